@@ -1,0 +1,83 @@
+/*
+ * lsd_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's LSD hot path
+ * (Pyrokine/LineSegmentDetector-SLAM, LSD/myLSD.cpp) used ONLY as the checker for the HIP
+ * implementation: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call
+ * it; nothing under linesegmentdetector-slam_amd/ links, imports or executes it.
+ *
+ * Pinning: the reference itself cannot be rebuilt in this image (it needs OpenCV and Eigen
+ * headers, both absent; hand-written stand-ins are not allowed), so the oracle is pinned
+ * against the reference outputs recorded in SURVEY.md section 8c / Appendix A (line counts,
+ * lit-pixel counts, mapCache sums for 8 maps and the %.17g map1 line list -- all produced by
+ * the unmodified reference) and, loosely, against the reference's own MATLAB-era golden
+ * files data/MaplinesInfo.txt / data/MaplineIm.txt.  See tests/test_oracle.py.
+ */
+#ifndef LSD_ORACLE_H
+#define LSD_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout-identical to structLinesInfo (LSD/baseFunc.h:33-44), sizeof == 80 */
+typedef struct {
+    double k, b, dx, dy, x1, y1, x2, y2, len;
+    int orient;
+} orc_line;
+
+/* per-seed trace record (one per RegionGrower call made from the seed loop, myLSD.cpp:225) */
+typedef struct {
+    int order_idx;   /* index into the sorted list */
+    int x, y;        /* seed */
+    int num;         /* region size returned by the first grow */
+    int outcome;     /* 0 small (myLSD.cpp:228), 1 refine failed (:237), 2 NFA reject (:242), 3 accepted */
+    int final_num;   /* region size after Refiner */
+    double logNFA;   /* after RectangleImprover (0 if not reached) */
+} orc_seed;
+
+typedef struct {
+    int w, h;             /* scaled size (myLSD.cpp:132-133) */
+    double *gauss;        /* [h*w]  GaussianSampler output */
+    double *mag;          /* [h*w]  myLSD.cpp:164 */
+    double *deg;          /* [h*w]  myLSD.cpp:172 */
+    uint8_t *used0;       /* [h*w]  usedMap right after the gradient loop (:166) */
+    uint8_t *used;        /* [h*w]  usedMap at the end of the seed loop */
+    int nb;               /* sorted-list length (cnt_binCell) */
+    int *ord_v, *ord_x, *ord_y;  /* [nb] sorted list (value, x, y) after qsort (:204) */
+    double maxGrad;
+    int n_seed;           /* number of trace records */
+    orc_seed *seeds;
+    double *recs;         /* [n_lines*12] accepted structRec before rescale: x1 y1 x2 y2 wid cX cY deg dx dy p prec */
+    /* counters */
+    long grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel_drops, rrr_oob_reads;
+} orc_debug;
+
+/* Restates mylsd::myLineSegmentDetector (LSD/myLSD.h:132, LSD/myLSD.cpp:129-376).
+ * map is IN-OUT (the reference mutates the caller's image, myLSD.cpp:135-142).
+ * lineIm (rows*cols, may be NULL) receives the 0/255 raster (:215, :343-355).
+ * *lines is malloc'ed (caller frees with orc_free), *n = len_linesInfo.
+ * dbg may be NULL; if not, arrays are malloc'ed and released with orc_debug_free. */
+int orc_lsd(uint8_t *map, int cols, int rows, size_t stride,
+            double sca, double sig, double angThre, double denThre, int pseBin,
+            uint8_t *lineIm, orc_line **lines, int *n, orc_debug *dbg);
+
+/* Restates mylsd::createMapCache (LSD/myLSD.cpp:11-127); out is rows*cols doubles. */
+int orc_map_cache(const uint8_t *map, int cols, int rows, size_t stride,
+                  double res, double z_occ_max_dis, double *out);
+
+/* Pins SURVEY 8a-Q4: glibc qsort + the reference comparator (myLSD.cpp:486-489) must equal a
+ * stable descending sort.  Returns 0 when the two orders agree on a pseudo-random list. */
+int orc_selftest_qsort_stable(int n, unsigned seed);
+
+/* the reference's log-gamma (myLSD.cpp:882-924) exposed for table checks */
+double orc_log_gamma(int x);
+
+void orc_free(void *p);
+void orc_debug_free(orc_debug *dbg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,148 @@
+"""ctypes front-end of the CPU ORACLE (oracle/lsd_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package never does.  The shared object is built by `make -C oracle`
+(__graft_entry__.build() does that).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcLine(C.Structure):  # == structLinesInfo, LSD/baseFunc.h:33-44
+    _fields_ = [(n, C.c_double) for n in ("k", "b", "dx", "dy", "x1", "y1", "x2", "y2", "len")] + [("orient", C.c_int)]
+
+
+LINE_DTYPE = np.dtype([("k", "f8"), ("b", "f8"), ("dx", "f8"), ("dy", "f8"), ("x1", "f8"), ("y1", "f8"),
+                       ("x2", "f8"), ("y2", "f8"), ("len", "f8"), ("orient", "i4"), ("_pad", "i4")])
+assert LINE_DTYPE.itemsize == 80 == C.sizeof(OrcLine)
+
+
+class OrcSeed(C.Structure):
+    _fields_ = [("order_idx", C.c_int), ("x", C.c_int), ("y", C.c_int), ("num", C.c_int),
+                ("outcome", C.c_int), ("final_num", C.c_int), ("logNFA", C.c_double)]
+
+
+SEED_DTYPE = np.dtype([("order_idx", "i4"), ("x", "i4"), ("y", "i4"), ("num", "i4"),
+                       ("outcome", "i4"), ("final_num", "i4"), ("logNFA", "f8")])
+assert SEED_DTYPE.itemsize == C.sizeof(OrcSeed)
+
+
+class OrcDebug(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int),
+                ("gauss", C.POINTER(C.c_double)), ("mag", C.POINTER(C.c_double)), ("deg", C.POINTER(C.c_double)),
+                ("used0", C.POINTER(C.c_uint8)), ("used", C.POINTER(C.c_uint8)),
+                ("nb", C.c_int),
+                ("ord_v", C.POINTER(C.c_int)), ("ord_x", C.POINTER(C.c_int)), ("ord_y", C.POINTER(C.c_int)),
+                ("maxGrad", C.c_double),
+                ("n_seed", C.c_int), ("seeds", C.POINTER(OrcSeed)),
+                ("recs", C.POINTER(C.c_double)),
+                ("grow_calls", C.c_long), ("grown_px", C.c_long), ("nfa_calls", C.c_long),
+                ("rrr_calls", C.c_long), ("rrr_passes", C.c_long), ("rrr_sentinel_drops", C.c_long),
+                ("rrr_oob_reads", C.c_long)]
+
+
+def build(asan=False):
+    target = "liblsd_oracle_asan.so" if asan else "liblsd_oracle.so"
+    subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+    return os.path.join(_HERE, target)
+
+
+def lib(path=None):
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or os.path.join(_HERE, "liblsd_oracle.so")
+    if not os.path.exists(p):
+        build()
+    L = C.CDLL(p)
+    L.orc_lsd.restype = C.c_int
+    L.orc_lsd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                          C.c_double, C.c_int, C.c_void_p, C.POINTER(C.POINTER(OrcLine)), C.POINTER(C.c_int),
+                          C.POINTER(OrcDebug)]
+    L.orc_map_cache.restype = C.c_int
+    L.orc_map_cache.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_void_p]
+    L.orc_selftest_qsort_stable.restype = C.c_int
+    L.orc_selftest_qsort_stable.argtypes = [C.c_int, C.c_uint]
+    L.orc_log_gamma.restype = C.c_double
+    L.orc_log_gamma.argtypes = [C.c_int]
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_debug_free.argtypes = [C.POINTER(OrcDebug)]
+    if path is None:
+        _LIB = L
+    return L
+
+
+DEFAULTS = dict(sca=0.3, sig=0.6, angThre=22.5, denThre=0.7, pseBin=1024)  # LSD/baseFunc.h:64-68
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def lsd(map_u8, sca=0.3, sig=0.6, angThre=22.5, denThre=0.7, pseBin=1024, want_lineim=True, debug=False,
+        _lib=None):
+    """Runs the oracle on a COPY-FREE uint8 image (it is mutated in place, like the reference does).
+
+    Returns dict(lines=structured array[LINE_DTYPE], lineIm=uint8[rows,cols] or None, dbg=dict or None).
+    """
+    L = _lib or lib()
+    assert map_u8.dtype == np.uint8 and map_u8.ndim == 2 and map_u8.flags.c_contiguous
+    rows, cols = map_u8.shape
+    line_im = np.zeros((rows, cols), np.uint8) if want_lineim else None
+    lines_p = C.POINTER(OrcLine)()
+    n = C.c_int(0)
+    dbg = OrcDebug() if debug else None
+    rc = L.orc_lsd(map_u8.ctypes.data, cols, rows, map_u8.strides[0], sca, sig, angThre, denThre, pseBin,
+                   line_im.ctypes.data if want_lineim else None, C.byref(lines_p), C.byref(n),
+                   C.byref(dbg) if debug else None)
+    if rc != 0:
+        raise RuntimeError("orc_lsd failed: %d" % rc)
+    lines = np.zeros(n.value, LINE_DTYPE)
+    if n.value:
+        C.memmove(lines.ctypes.data, lines_p, 80 * n.value)
+        lines["_pad"] = 0
+    L.orc_free(lines_p)
+    out = {"lines": lines, "lineIm": line_im, "dbg": None}
+    if debug:
+        w, h = dbg.w, dbg.h
+        npx = w * h
+        d = {"w": w, "h": h, "nb": dbg.nb, "maxGrad": dbg.maxGrad}
+        if npx:
+            d["gauss"] = _arr(dbg.gauss, npx, np.float64).reshape(h, w)
+            d["mag"] = _arr(dbg.mag, npx, np.float64).reshape(h, w)
+            d["deg"] = _arr(dbg.deg, npx, np.float64).reshape(h, w)
+            d["used0"] = _arr(dbg.used0, npx, np.uint8).reshape(h, w)
+            d["used"] = _arr(dbg.used, npx, np.uint8).reshape(h, w)
+            d["ord_v"] = _arr(dbg.ord_v, dbg.nb, np.int32)
+            d["ord_x"] = _arr(dbg.ord_x, dbg.nb, np.int32)
+            d["ord_y"] = _arr(dbg.ord_y, dbg.nb, np.int32)
+            seeds = np.zeros(dbg.n_seed, SEED_DTYPE)
+            if dbg.n_seed:
+                C.memmove(seeds.ctypes.data, dbg.seeds, SEED_DTYPE.itemsize * dbg.n_seed)
+            d["seeds"] = seeds
+            d["recs"] = _arr(dbg.recs, 12 * n.value, np.float64).reshape(n.value, 12)
+        for k in ("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
+                  "rrr_oob_reads"):
+            d[k] = getattr(dbg, k)
+        L.orc_debug_free(C.byref(dbg))
+        out["dbg"] = d
+    return out
+
+
+def map_cache(map_u8, res, z_occ_max_dis=1.0, _lib=None):
+    """Oracle for mylsd::createMapCache (LSD/myLSD.cpp:11-127); z_occ_max_dis from baseFunc.h:60."""
+    L = _lib or lib()
+    assert map_u8.dtype == np.uint8 and map_u8.ndim == 2 and map_u8.flags.c_contiguous
+    rows, cols = map_u8.shape
+    out = np.zeros((rows, cols), np.float64)
+    rc = L.orc_map_cache(map_u8.ctypes.data, cols, rows, map_u8.strides[0], res, z_occ_max_dis, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_map_cache failed: %d" % rc)
+    return out

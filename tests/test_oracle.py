@@ -1,0 +1,186 @@
+"""Pins the CPU oracle (oracle/lsd_oracle.c) to the reference.
+
+The reference cannot be rebuilt in this image (OpenCV/Eigen headers absent), so the pins are
+the reference outputs recorded in SURVEY.md 8c / Appendix A (tests/golden/known_answers.json)
+plus the reference's own MATLAB-era golden files for data/mapValue.txt (loose).
+"""
+import numpy as np
+import pytest
+
+from conftest import tile2048
+
+FIXTURES = ["map1", "mapValue", "aisle1", "aisle2", "aisle3", "f3key", "f4key"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_counts_match_reference(name, maps, maps_meta, known, oracle):
+    nl, lit, csum, ccnt = known["counts"][name]
+    m = maps[name].copy()
+    mc = oracle.map_cache(m, maps_meta[name]["res"])      # createMapCache runs BEFORE LSD (Q2)
+    r = oracle.lsd(m)
+    assert len(r["lines"]) == nl
+    assert int((r["lineIm"] == 255).sum()) == lit
+    assert set(np.unique(r["lineIm"])) <= {0, 255}
+    assert abs(float(mc.sum()) - csum) < 1e-5
+    assert int((mc < 1.0).sum()) == ccnt
+
+
+def test_tile2048_matches_reference(maps, known, oracle):
+    nl, lit, csum, ccnt = known["counts"]["tile2048"]
+    m = tile2048(maps["aisle1"])
+    mc = oracle.map_cache(m, 0.025)
+    r = oracle.lsd(m)
+    assert len(r["lines"]) == nl
+    assert int((r["lineIm"] == 255).sum()) == lit
+    assert abs(float(mc.sum()) - csum) < 1e-4
+    assert int((mc < 1.0).sum()) == ccnt
+
+
+def test_map1_line_list_bit_exact(maps, known, oracle):
+    """Appendix A prints the reference's map1 lines with %.17g (round-trip exact)."""
+    r = oracle.lsd(maps["map1"].copy())
+    gold = known["map1_lines"]
+    assert len(r["lines"]) == len(gold)
+    for got, row in zip(r["lines"], gold):
+        for f, s in zip(known["map1_lines_fields"], row):
+            if f == "orient":
+                assert int(got[f]) == int(s)
+            else:
+                assert float(got[f]) == float(s), (f, got[f], s)
+
+
+def test_map1_stage_counters(maps, known, oracle):
+    c = known["map1_counters"]
+    d = oracle.lsd(maps["map1"].copy(), debug=True)["dbg"]
+    assert d["nb"] == c["sorted_px"]
+    assert d["grow_calls"] == c["grow_calls"]
+    assert d["grown_px"] == c["grown_px"]
+    assert d["nfa_calls"] == c["nfa_calls"]
+    assert (d["rrr_calls"], d["rrr_passes"]) == (c["rrr_calls"], c["rrr_passes"])
+    seeds = d["seeds"]
+    assert len(seeds) == c["seeds"]
+    assert int((seeds["outcome"] == 0).sum()) == c["small_drops"]
+    assert int((seeds["outcome"] == 2).sum()) == c["nfa_rejects"]
+    assert int(seeds["num"].max()) == c["max_region"]
+    assert d["rrr_oob_reads"] == 0          # the reference's UB read (Q6) never fires on fixtures
+
+
+def test_map2_is_map1(maps):
+    assert "map2" not in maps   # make_fixtures.py asserts byte-identity and stores it once
+
+
+def test_inplace_remap_and_border(maps, oracle):
+    """Q2: the caller's image is mutated for y>=1,x>=1 only; row 0 / col 0 keep raw values."""
+    src = maps["map1"]
+    m = src.copy()
+    m[0, 5] = 1; m[7, 0] = 255; m[3, 3] = 1; m[4, 4] = 255
+    ref = m.copy()
+    oracle.lsd(m, want_lineim=False)
+    assert m[0, 5] == 1 and m[7, 0] == 255
+    assert m[3, 3] == 255 and m[4, 4] == 0
+    inner = ref[1:, 1:]
+    exp = np.where(inner == 1, 255, np.where(inner == 255, 0, inner))
+    assert np.array_equal(m[1:, 1:], exp)
+    assert np.array_equal(m[0, :], ref[0, :]) and np.array_equal(m[:, 0], ref[:, 0])
+
+
+def test_scaled_border_is_zero(maps, oracle):
+    """Q3: row 0 / col 0 of mag, deg, used stay 0."""
+    d = oracle.lsd(maps["aisle1"].copy(), debug=True)["dbg"]
+    for k in ("mag", "deg", "used0"):
+        assert not d[k][0, :].any() and not d[k][:, 0].any()
+
+
+def test_sort_is_stable_descending(maps, oracle):
+    """Q4: descending by bin value, raster order (y-major, then x) among ties."""
+    d = oracle.lsd(maps["aisle2"].copy(), debug=True)["dbg"]
+    v, x, y = d["ord_v"].astype(np.int64), d["ord_x"].astype(np.int64), d["ord_y"].astype(np.int64)
+    assert len(v) == d["nb"] > 0
+    assert v.max() <= 1024 and v.min() >= 1
+    key = (1024 - v) * (1 << 40) + y * (1 << 20) + x
+    assert np.all(np.diff(key) > 0)
+    zoom = 1.0 * 1024 / d["maxGrad"]
+    vv = np.floor(d["mag"] * zoom).astype(np.int64).clip(max=1024)
+    assert int((vv != 0).sum()) == d["nb"]
+    assert np.array_equal(vv[y, x], v)
+
+
+def test_glibc_qsort_comparator_is_stable(oracle):
+    """Pins the libc behaviour Q4 relies on: qsort + the reference comparator == stable order."""
+    for n, seed in ((10, 1), (1000, 2), (50000, 3)):
+        assert oracle.lib().orc_selftest_qsort_stable(n, seed) == 0
+
+
+def test_used_map_values(maps, oracle):
+    d = oracle.lsd(maps["mapValue"].copy(), debug=True)["dbg"]
+    assert set(np.unique(d["used"])) <= {0, 1, 2}
+    # accepted/rejected regions only ever add marks
+    assert np.all((d["used0"] == 1) <= (d["used"] == 1))
+
+
+def test_loose_matlab_golden(maps, oracle):
+    """The reference's own golden files (data/MaplinesInfo.txt, MaplineIm.txt) come from the author's
+    MATLAB prototype: same walls, endpoints possibly swapped, a few lines differ."""
+    r = oracle.lsd(maps["mapValue"].copy())
+    gold = maps["matlab_MaplinesInfo"]          # k b dx dy x1 y1 x2 y2 len orient
+    L = r["lines"]
+    matched = 0
+    for g in gold:
+        a = np.array([g[4], g[5]]); b = np.array([g[6], g[7]])
+        best = 1e9
+        for l in L:
+            p = np.array([l["x1"], l["y1"]]); q = np.array([l["x2"], l["y2"]])
+            e = min(max(np.abs(a - p).max(), np.abs(b - q).max()), max(np.abs(a - q).max(), np.abs(b - p).max()))
+            best = min(best, e)
+        matched += best <= 0.5
+    assert matched >= 34, matched
+    lit = maps["matlab_MaplineIm_lit_yx"]
+    im = r["lineIm"]
+    near = 0
+    for y, x in lit:
+        y0, y1, x0, x1 = max(y - 2, 0), y + 3, max(x - 2, 0), x + 3
+        near += bool(im[y0:y1, x0:x1].any())
+    assert near >= 0.9 * len(lit), (near, len(lit))
+
+
+def test_blank_and_tiny_images(oracle):
+    r = oracle.lsd(np.zeros((64, 80), np.uint8))
+    assert len(r["lines"]) == 0 and not r["lineIm"].any()
+    r = oracle.lsd(np.zeros((5, 5), np.uint8))
+    assert len(r["lines"]) == 0
+
+
+def test_synthetic_square_is_deterministic(oracle):
+    rng = np.random.default_rng(5)
+    m = np.zeros((300, 400), np.uint8)
+    m[60:240, 80] = 1; m[60:240, 320] = 1; m[60, 80:321] = 1; m[240, 80:321] = 1
+    m[rng.integers(1, 299, 200), rng.integers(1, 399, 200)] = 1
+    a = oracle.lsd(m.copy(), debug=True)
+    b = oracle.lsd(m.copy(), debug=True)
+    assert len(a["lines"]) >= 4
+    assert a["lines"].tobytes() == b["lines"].tobytes()
+    assert np.array_equal(a["dbg"]["used"], b["dbg"]["used"])
+
+
+def test_oracle_asan_clean(maps, oracle):
+    """CPU-only sanitizer pass (GPU sanitizers are unavailable on the pool)."""
+    import subprocess, sys, os
+    so = oracle.build(asan=True)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from oracle import oracle\n"
+        "L = oracle.lib(%r)\n"
+        "z = np.load(%r)\n"
+        "for k in ('map1', 'aisle1'):\n"
+        "    r = oracle.lsd(z[k].copy(), debug=True, _lib=L)\n"
+        "    oracle.map_cache(z[k].copy(), 0.05, _lib=L)\n"
+        "print('OK')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), so,
+         os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps.npz"))
+    import glob
+    asan = sorted(glob.glob("/usr/lib/gcc/x86_64-linux-gnu/*/libasan.so"))
+    if not asan:
+        pytest.skip("libasan not installed")
+    env = dict(os.environ, LD_PRELOAD=asan[-1], ASAN_OPTIONS="detect_leaks=0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
