@@ -1,0 +1,137 @@
+/*
+ * lsd_hip.h -- C ABI of liblsdhip.so, the MI355X (gfx950) implementation of the LSD hot path of
+ * Pyrokine/LineSegmentDetector-SLAM.
+ *
+ * The reference has no FFI layer: its boundary for this path is the C++ free function
+ *     structLSD mylsd::myLineSegmentDetector(Mat MapGray, int oriMapCol, int oriMapRow,
+ *                                            double sca, double sig, double angThre,
+ *                                            double denThre, int pseBin);      LSD/myLSD.h:132
+ * (definition LSD/myLSD.cpp:129-376), called from LSD/main_on_windows.cpp:70 and
+ * LSD/main_on_linux.cpp:132.  Every entry point below states the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++/torch types; status codes, no exceptions.
+ * The C++ adapter with the reference's own names lives in include/myLSD.h.
+ *
+ * There is NO CPU fallback: lsd_create() fails with LSD_ERR_NO_DEVICE when no gfx950 GPU is
+ * visible, and nothing in this library computes the path on the host.
+ */
+#ifndef LSD_HIP_H
+#define LSD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSD_ABI_VERSION 1
+
+/* status codes */
+enum {
+    LSD_OK = 0,
+    LSD_ERR_INVALID = 1,        /* bad argument */
+    LSD_ERR_NO_DEVICE = 2,      /* no usable HIP device (the library never falls back to the CPU) */
+    LSD_ERR_HIP = 3,            /* a HIP runtime call failed; see lsd_last_error() */
+    LSD_ERR_UNSUPPORTED = 4,    /* parameter outside the implemented range (e.g. pseBin > 1024) */
+    LSD_ERR_CAPACITY = 5,       /* more lines than max_lines in at least one image */
+    LSD_ERR_NOMEM = 6
+};
+
+/* The five LSD knobs of myLineSegmentDetector (LSD/myLSD.h:132); defaults LSD/baseFunc.h:64-68. */
+typedef struct lsd_params {
+    double sca;      /* 0.3  */
+    double sig;      /* 0.6  */
+    double angThre;  /* 22.5 */
+    double denThre;  /* 0.7  */
+    int pseBin;      /* 1024 */
+} lsd_params;
+
+/* Layout-identical to structLinesInfo (LSD/baseFunc.h:33-44): 9 doubles + int, sizeof == 80. */
+typedef struct lsd_line {
+    double k, b, dx, dy, x1, y1, x2, y2, len;
+    int orient;
+} lsd_line;
+
+typedef struct lsd_ctx lsd_ctx;
+
+/* --- lifetime ------------------------------------------------------------------------ */
+/* Creates a context bound to HIP device `device` (one context per GPU / per process rank). */
+int lsd_create(lsd_ctx **out, int device);
+void lsd_destroy(lsd_ctx *ctx);
+const char *lsd_strerror(int status);
+/* Text of the last HIP failure seen by this context ("" if none). */
+const char *lsd_last_error(const lsd_ctx *ctx);
+/* Fills the reference defaults (LSD/baseFunc.h:64-68). */
+void lsd_default_params(lsd_params *p);
+int lsd_abi_version(void);
+/* Frees buffers returned through lines_out. */
+void lsd_free(void *p);
+
+/* --- the hot path, host buffers -------------------------------------------------------- */
+/* Replaces mylsd::myLineSegmentDetector (LSD/myLSD.h:132, LSD/myLSD.cpp:129).
+ *   map        IN-OUT rows x cols uint8, row pitch `stride` bytes.  As in the reference the
+ *              caller's image is rewritten (1 -> 255, 255 -> 0 for y >= 1, x >= 1; myLSD.cpp:135-142).
+ *   line_im    rows x cols uint8 (pitch line_im_stride), receives structLSD.lineIm (0/255), or NULL.
+ *   lines_out  receives a malloc'ed array of *n_lines lsd_line (structLSD.linesInfo; free with lsd_free).
+ * Blocking; uses the context's own stream. */
+int lsd_run(lsd_ctx *ctx, uint8_t *map, int cols, int rows, size_t stride, const lsd_params *p,
+            uint8_t *line_im, size_t line_im_stride, lsd_line **lines_out, int *n_lines);
+
+/* Batch of n equally sized images packed back to back (image i at maps + i*rows*cols, pitch cols).
+ * offsets_out[n+1] receives the prefix sums of the per-image line counts; *lines_out the
+ * concatenated lines (malloc'ed).  maps are rewritten like lsd_run does.  line_ims may be NULL. */
+int lsd_run_batch(lsd_ctx *ctx, uint8_t *maps, int n, int cols, int rows, const lsd_params *p,
+                  uint8_t *line_ims, lsd_line **lines_out, int *offsets_out);
+
+/* --- the hot path, device-resident batch ------------------------------------------------ */
+/* Same computation on buffers that already live in HBM (e.g. torch tensors' data_ptr()).
+ *   d_maps     n x rows x cols uint8, read-only unless LSD_FLAG_WRITEBACK_MAP is set
+ *   d_line_ims n x rows x cols uint8 or NULL
+ *   d_lines    n x max_lines lsd_line (image i's lines start at d_lines + i*max_lines)
+ *   d_counts   n int32 line counts (a count > max_lines means that image overflowed: LSD_ERR_CAPACITY
+ *              is reported by lsd_batch_status, the first max_lines lines are valid)
+ *   stream     hipStream_t on which to enqueue (NULL = the context's stream).  Asynchronous:
+ *              returns after enqueueing; workspace is (re)allocated before the first launch only
+ *              when (n, cols, rows) grew. */
+#define LSD_FLAG_WRITEBACK_MAP 1u
+int lsd_enqueue_batch_device(lsd_ctx *ctx, uint8_t *d_maps, int n, int cols, int rows,
+                             const lsd_params *p, unsigned flags, uint8_t *d_line_ims,
+                             lsd_line *d_lines, int max_lines, int32_t *d_counts, void *stream);
+/* Pre-sizes the workspace so that lsd_enqueue_batch_device never allocates. */
+int lsd_reserve(lsd_ctx *ctx, int n, int cols, int rows);
+/* Blocks until the stream used by the last enqueue is idle. */
+int lsd_synchronize(lsd_ctx *ctx);
+
+/* --- introspection used by the parity tests and the bench ------------------------------- */
+/* Scaled size of a cols x rows map: w = floor(cols*sca), h = floor(rows*sca) (myLSD.cpp:132-133). */
+void lsd_scaled_size(int cols, int rows, double sca, int *w, int *h);
+
+/* Stops the pipeline after a stage (parity tests of intermediate maps); 0 = run everything. */
+enum { LSD_STAGE_ALL = 0, LSD_STAGE_GAUSS = 1, LSD_STAGE_GRAD = 2, LSD_STAGE_SORT = 3, LSD_STAGE_REGION = 4 };
+int lsd_set_stop_after(lsd_ctx *ctx, int stage);
+/* Enables the per-seed trace buffer (LSD_DBG_SEEDS); costs one record store per grown seed. */
+int lsd_set_trace(lsd_ctx *ctx, int on);
+
+/* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
+ *   GAUSS/MAG/DEG  h*w doubles      (GaussImage / magMap / degMap, myLSD.cpp:143-147)
+ *   STATE          h*w uint32       low 2 bits = usedMap value (myLSD.cpp:145), rest = curMap stamp
+ *   ORDER          nb uint32        sorted seed list, element = y*w + x (binCell after qsort, :204)
+ *   ORDER_VAL      nb uint16        its bin values
+ *   NB             1 int32          len_binCell
+ *   MAXGRAD        1 double
+ *   RECS           count*12 doubles accepted structRec before rescale (x1 y1 x2 y2 wid cX cY deg dx dy p prec)
+ *   SEEDS          n_seed records {int order_idx, x, y, num, outcome, final_num; double logNFA}
+ *   NSEED          1 int32
+ *   STATS          8 int64          grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, list_spills
+ * Returns LSD_ERR_INVALID if `bytes` is smaller than the item. */
+enum { LSD_DBG_GAUSS = 1, LSD_DBG_MAG, LSD_DBG_DEG, LSD_DBG_STATE, LSD_DBG_ORDER, LSD_DBG_ORDER_VAL,
+       LSD_DBG_NB, LSD_DBG_MAXGRAD, LSD_DBG_RECS, LSD_DBG_SEEDS, LSD_DBG_NSEED, LSD_DBG_STATS };
+int lsd_debug_fetch(lsd_ctx *ctx, int image, int what, void *out, size_t bytes);
+
+/* Per-kernel device time (ms) of the last lsd_run/lsd_run_batch, measured with HIP events on the
+ * context's stream: [0] gauss, [1] gradient, [2] sort, [3] region, [4] lines, [5] total. */
+int lsd_last_timings(lsd_ctx *ctx, float ms_out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSD_HIP_H */

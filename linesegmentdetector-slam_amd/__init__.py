@@ -1,0 +1,272 @@
+"""linesegmentdetector-slam_amd -- MI355X-native LSD line-feature extractor.
+
+Python host-side mirror of the reference interface for the hot path
+(``mylsd::myLineSegmentDetector``, LSD/myLSD.h:132) on top of the C ABI of ``liblsdhip.so``
+(include/lsd_hip.h).  The directory name contains a hyphen, import it with::
+
+    lsd = importlib.import_module("linesegmentdetector-slam_amd")
+
+There is NO CPU fallback: without the built HIP library, or without a GPU, every entry point
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsdhip.so")
+
+# ---- constants mirrored from include/lsd_hip.h -------------------------------------------------
+LSD_OK, LSD_ERR_INVALID, LSD_ERR_NO_DEVICE, LSD_ERR_HIP, LSD_ERR_UNSUPPORTED, LSD_ERR_CAPACITY, LSD_ERR_NOMEM = range(7)
+LSD_FLAG_WRITEBACK_MAP = 1
+STAGE_ALL, STAGE_GAUSS, STAGE_GRAD, STAGE_SORT, STAGE_REGION = range(5)
+(DBG_GAUSS, DBG_MAG, DBG_DEG, DBG_STATE, DBG_ORDER, DBG_ORDER_VAL, DBG_NB, DBG_MAXGRAD, DBG_RECS, DBG_SEEDS,
+ DBG_NSEED, DBG_STATS) = range(1, 13)
+
+# LSD defaults, LSD/baseFunc.h:64-68
+lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin = 0.3, 0.6, 22.5, 0.7, 1024
+
+
+class lsd_params(C.Structure):
+    _fields_ = [("sca", C.c_double), ("sig", C.c_double), ("angThre", C.c_double), ("denThre", C.c_double),
+                ("pseBin", C.c_int)]
+
+
+class lsd_line(C.Structure):  # == structLinesInfo, LSD/baseFunc.h:33-44
+    _fields_ = [(n, C.c_double) for n in ("k", "b", "dx", "dy", "x1", "y1", "x2", "y2", "len")] + [("orient", C.c_int)]
+
+
+# numpy view of structLinesInfo (80 bytes incl. tail padding)
+LINE_DTYPE = np.dtype([("k", "f8"), ("b", "f8"), ("dx", "f8"), ("dy", "f8"), ("x1", "f8"), ("y1", "f8"),
+                       ("x2", "f8"), ("y2", "f8"), ("len", "f8"), ("orient", "i4"), ("_pad", "i4")])
+SEED_DTYPE = np.dtype([("order_idx", "i4"), ("x", "i4"), ("y", "i4"), ("num", "i4"), ("outcome", "i4"),
+                       ("final_num", "i4"), ("logNFA", "f8")])
+assert LINE_DTYPE.itemsize == 80 == C.sizeof(lsd_line)
+
+
+class LsdError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("lsd_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads liblsdhip.so (built by __graft_entry__.build() / make -C csrc).  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("liblsdhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "-- there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    vp, i, sz, dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+    L.lsd_create.restype = i; L.lsd_create.argtypes = [C.POINTER(vp), i]
+    L.lsd_destroy.restype = None; L.lsd_destroy.argtypes = [vp]
+    L.lsd_strerror.restype = C.c_char_p; L.lsd_strerror.argtypes = [i]
+    L.lsd_last_error.restype = C.c_char_p; L.lsd_last_error.argtypes = [vp]
+    L.lsd_default_params.restype = None; L.lsd_default_params.argtypes = [C.POINTER(lsd_params)]
+    L.lsd_abi_version.restype = i; L.lsd_abi_version.argtypes = []
+    L.lsd_free.restype = None; L.lsd_free.argtypes = [vp]
+    L.lsd_run.restype = i
+    L.lsd_run.argtypes = [vp, vp, i, i, sz, C.POINTER(lsd_params), vp, sz, C.POINTER(vp), C.POINTER(i)]
+    L.lsd_run_batch.restype = i
+    L.lsd_run_batch.argtypes = [vp, vp, i, i, i, C.POINTER(lsd_params), vp, C.POINTER(vp), C.POINTER(i)]
+    L.lsd_enqueue_batch_device.restype = i
+    L.lsd_enqueue_batch_device.argtypes = [vp, vp, i, i, i, C.POINTER(lsd_params), C.c_uint, vp, vp, i, vp, vp]
+    L.lsd_reserve.restype = i; L.lsd_reserve.argtypes = [vp, i, i, i]
+    L.lsd_synchronize.restype = i; L.lsd_synchronize.argtypes = [vp]
+    L.lsd_scaled_size.restype = None; L.lsd_scaled_size.argtypes = [i, i, dbl, C.POINTER(i), C.POINTER(i)]
+    L.lsd_set_stop_after.restype = i; L.lsd_set_stop_after.argtypes = [vp, i]
+    L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
+    L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
+    L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    if path is None:
+        _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
+                    "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
+                    "lsd_debug_fetch", "lsd_last_timings"]
+
+
+def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
+    return lsd_params(float(sca), float(sig), float(angThre), float(denThre), int(pseBin))
+
+
+def scaled_size(cols, rows, sca=lsd_sca):
+    w, h = C.c_int(), C.c_int()
+    load_library().lsd_scaled_size(cols, rows, sca, C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+class Context:
+    """One lsd_ctx: one GPU, one stream, one HBM workspace (one per process rank)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.lsd_create(C.byref(h), int(device))
+        if st != LSD_OK:
+            raise LsdError(st, self.L.lsd_strerror(st).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, allow=()):
+        if st != LSD_OK and st not in allow:
+            raise LsdError(st, self.L.lsd_strerror(st).decode() + " / " + self.L.lsd_last_error(self.h).decode())
+        return st
+
+    # -- host-buffer entry points -----------------------------------------------------------------
+    def run(self, map_u8, params=None, want_lineim=True):
+        """lsd_run on a C-contiguous uint8 image; the image is rewritten in place like the reference does."""
+        assert map_u8.dtype == np.uint8 and map_u8.ndim == 2
+        rows, cols = map_u8.shape
+        p = params or make_params()
+        line_im = np.zeros((rows, cols), np.uint8) if want_lineim else None
+        lines_p, n = C.c_void_p(), C.c_int()
+        self._chk(self.L.lsd_run(self.h, map_u8.ctypes.data, cols, rows, map_u8.strides[0], C.byref(p),
+                                 line_im.ctypes.data if want_lineim else None, cols, C.byref(lines_p), C.byref(n)))
+        lines = np.zeros(n.value, LINE_DTYPE)
+        if n.value:
+            C.memmove(lines.ctypes.data, lines_p, 80 * n.value)
+            lines["_pad"] = 0
+        self.L.lsd_free(lines_p)
+        return lines, line_im
+
+    def run_batch(self, maps_u8, params=None, want_lineim=True):
+        """lsd_run_batch on an [n, rows, cols] uint8 array (rewritten in place)."""
+        assert maps_u8.dtype == np.uint8 and maps_u8.ndim == 3 and maps_u8.flags.c_contiguous
+        n, rows, cols = maps_u8.shape
+        p = params or make_params()
+        line_ims = np.zeros((n, rows, cols), np.uint8) if want_lineim else None
+        lines_p = C.c_void_p()
+        offs = (C.c_int * (n + 1))()
+        self._chk(self.L.lsd_run_batch(self.h, maps_u8.ctypes.data, n, cols, rows, C.byref(p),
+                                       line_ims.ctypes.data if want_lineim else None, C.byref(lines_p), offs))
+        offsets = np.frombuffer(offs, np.int32).copy()
+        lines = np.zeros(int(offsets[-1]), LINE_DTYPE)
+        if len(lines):
+            C.memmove(lines.ctypes.data, lines_p, 80 * len(lines))
+            lines["_pad"] = 0
+        self.L.lsd_free(lines_p)
+        return lines, offsets, line_ims
+
+    # -- device-resident batch --------------------------------------------------------------------
+    def enqueue_device(self, d_maps, n, cols, rows, d_lines, max_lines, d_counts, d_line_ims=None, params=None,
+                       flags=0, stream=None):
+        """Pointers are raw device addresses (e.g. torch tensor .data_ptr()); asynchronous."""
+        p = params or make_params()
+        return self._chk(self.L.lsd_enqueue_batch_device(self.h, d_maps, n, cols, rows, C.byref(p), flags, d_line_ims,
+                                                         d_lines, max_lines, d_counts, stream))
+
+    def reserve(self, n, cols, rows):
+        self._chk(self.L.lsd_reserve(self.h, n, cols, rows))
+
+    def synchronize(self):
+        self._chk(self.L.lsd_synchronize(self.h))
+
+    def timings(self):
+        ms = (C.c_float * 6)()
+        self._chk(self.L.lsd_last_timings(self.h, ms))
+        return dict(zip(("gauss", "gradient", "sort", "region", "lines", "total"), [float(x) for x in ms]))
+
+    # -- introspection ----------------------------------------------------------------------------
+    def set_stop_after(self, stage):
+        self._chk(self.L.lsd_set_stop_after(self.h, stage))
+
+    def set_trace(self, on):
+        self._chk(self.L.lsd_set_trace(self.h, 1 if on else 0))
+
+    def fetch(self, image, what, shape_wh):
+        """Returns the intermediate `what` (DBG_*) of image `image` of the last run as a numpy array."""
+        w, h = shape_wh
+        npx = w * h
+
+        def get(kind, dtype, count):
+            a = np.zeros(max(count, 1), dtype)
+            self._chk(self.L.lsd_debug_fetch(self.h, image, kind, a.ctypes.data, a.nbytes))
+            return a[:count]
+
+        if what in (DBG_GAUSS, DBG_MAG, DBG_DEG):
+            return get(what, np.float64, npx).reshape(h, w)
+        if what == DBG_STATE:
+            return get(what, np.uint32, npx).reshape(h, w)
+        if what == DBG_NB:
+            return int(get(what, np.int32, 1)[0])
+        if what == DBG_NSEED:
+            return int(get(what, np.int32, 1)[0])
+        if what == DBG_MAXGRAD:
+            return float(get(what, np.float64, 1)[0])
+        if what == DBG_ORDER:
+            return get(what, np.uint32, npx)[:self.fetch(image, DBG_NB, shape_wh)]
+        if what == DBG_ORDER_VAL:
+            return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
+        if what == DBG_STATS:
+            v = get(what, np.int64, 8)
+            return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
+                             "rrr_oob_reads", "list_spills"), [int(x) for x in v]))
+        if what == DBG_SEEDS:
+            ns = self.fetch(image, DBG_NSEED, shape_wh)
+            return get(what, SEED_DTYPE, ns)
+        raise ValueError(what)
+
+    def fetch_recs(self, image, count):
+        a = np.zeros(max(count * 12, 1), np.float64)
+        self._chk(self.L.lsd_debug_fetch(self.h, image, DBG_RECS, a.ctypes.data, a.nbytes))
+        return a[:count * 12].reshape(count, 12)
+
+
+# ---- the reference's own names (LSD/myLSD.h:123-132) ----------------------------------------------
+class structLSD:
+    """structLSD (LSD/myLSD.h:123-127): lineIm (CV_8UC1 rows x cols, 0/255), linesInfo, len_linesInfo."""
+
+    def __init__(self, lineIm, linesInfo):
+        self.lineIm = lineIm
+        self.linesInfo = linesInfo
+        self.len_linesInfo = len(linesInfo)
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def myLineSegmentDetector(MapGray, oriMapCol, oriMapRow, sca, sig, angThre, denThre, pseBin, ctx=None):
+    """mylsd::myLineSegmentDetector (LSD/myLSD.h:132, LSD/myLSD.cpp:129): same argument meaning, same
+    in-place rewrite of MapGray, returns structLSD.  No validation beyond the C ABI's, like the reference."""
+    if MapGray.shape != (oriMapRow, oriMapCol):
+        raise LsdError(LSD_ERR_INVALID, "MapGray must be oriMapRow x oriMapCol")
+    ctx = ctx or default_context()
+    lines, line_im = ctx.run(MapGray, make_params(sca, sig, angThre, denThre, pseBin))
+    return structLSD(line_im, lines)
+
+
+def runLSD(MapGray, oriMapCol=None, oriMapRow=None, sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre,
+           denThre=lsd_denThre, pseBin=pseBin, ctx=None):
+    """`runLSD` is the name BASELINE.json's north_star uses; the reference has no such symbol
+    (SURVEY section 0.1).  It is an alias of myLineSegmentDetector with the baseFunc.h defaults."""
+    rows, cols = MapGray.shape
+    return myLineSegmentDetector(MapGray, oriMapCol or cols, oriMapRow or rows, sca, sig, angThre, denThre, pseBin, ctx)

@@ -1,0 +1,137 @@
+// k_gauss.hip -- K1: fused value remap + separable Gaussian x0.3 downsample (gfx950).
+//
+// Replaces the prologue remap (LSD/myLSD.cpp:135-142) and GaussianSampler (LSD/myLSD.cpp:378-484).
+// One workgroup produces a 32x32 tile of the scaled image: the (reflected, remapped) u8 source
+// window is staged in LDS with coalesced row-major loads, the x-pass writes an fp64 LDS strip,
+// the y-pass reads it back column-wise.  The reference's aux[H][w] image never exists in HBM.
+//
+// Bit-exactness: same taps (computed on the host with the host libm), same accumulation order
+// (newVal += pix * ker[i], i ascending), fp64, no FMA contraction (-ffp-contract=off).
+#include "lsd_internal.h"
+
+namespace lsdhip {
+
+constexpr int TW = 32, TH = 32, NT = 256;
+
+__device__ __forceinline__ int reflect_idx(int j, int lim) {  // myLSD.cpp:436-443
+    const int dou = 2 * lim;
+    while (j < 0) j += dou;
+    while (j >= dou) j -= dou;
+    if (j >= lim) j = dou - j - 1;
+    return j;
+}
+
+__device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 / :460
+    return cvt_x86(floor(x / sca + 0.5));
+}
+
+__global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
+                                              const double* __restrict__ taps_g, int W, int H, int w, int h,
+                                              double sca, int tapR, int IWp, int IHmax) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int hSize = 2 * tapR + 1;
+    double* aux = reinterpret_cast<double*>(smem);                // [IHmax][TW]
+    double* taps = aux + (size_t)IHmax * TW;                      // [3][hSize]
+    uint8_t* tile = reinterpret_cast<uint8_t*>(taps + 3 * hSize); // [IHmax][IWp]
+
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
+    const size_t img = blockIdx.z;
+    const uint8_t* src = in + img * (size_t)W * H;
+    double* dst = out + img * (size_t)w * h;
+
+    const int Xl = min(X0 + TW - 1, w - 1), Yl = min(Y0 + TH - 1, h - 1);
+    const int c0 = centre_of(X0, sca) - tapR, c1 = centre_of(Xl, sca) + tapR;
+    const int r0 = centre_of(Y0, sca) - tapR, r1 = centre_of(Yl, sca) + tapR;
+    const int IW = c1 - c0 + 1, IH = r1 - r0 + 1;
+
+    for (int i = tid; i < 3 * hSize; i += NT) taps[i] = taps_g[i];
+
+    // stage the source window: lanes walk a row (coalesced), 4 rows per pass
+    {
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int r = ty; r < IH; r += 4) {
+            const int gy = reflect_idx(r0 + r, H);
+            const uint8_t* row = src + (size_t)gy * W;
+            for (int c = tx; c < IW; c += 64) {
+                const int gx = reflect_idx(c0 + c, W);
+                uint8_t v = row[gx];
+                if (gy >= 1 && gx >= 1) {            // myLSD.cpp:135-142 (row 0 / col 0 keep raw values, Q2)
+                    if (v == 1) v = 255; else if (v == 255) v = 0;
+                }
+                tile[r * IWp + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // x-pass (myLSD.cpp:420-448): aux[r][X] = sum_i tile[r][xc-h+i] * ker[X%3][i]
+    const int X = tid & (TW - 1);
+    const int gX = X0 + X;
+    {
+        const int cb = centre_of(gX, sca) - tapR - c0;            // first tap's column inside the window
+        const double* ker = taps + (gX % 3) * hSize;
+        if (gX < w) {
+            for (int r = tid / TW; r < IH; r += NT / TW) {
+                const uint8_t* t = tile + r * IWp + cb;
+                double v = 0;
+                for (int i = 0; i < hSize; i++) v += (double)(int)t[i] * ker[i];
+                aux[r * TW + X] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // y-pass (myLSD.cpp:452-482): out[Y][X] = sum_i aux[yc-h+i][X] * ker[Y%3][i]
+    if (gX < w) {
+        for (int Y = tid / TW; Y < TH; Y += NT / TW) {
+            const int gY = Y0 + Y;
+            if (gY >= h) break;
+            const int rb = centre_of(gY, sca) - tapR - r0;
+            const double* ker = taps + (gY % 3) * hSize;
+            double v = 0;
+            for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
+            dst[(size_t)gY * w + gX] = v;
+        }
+    }
+}
+
+// Observable side effect of the reference: the caller's image is rewritten in place (myLSD.cpp:135-142).
+__global__ __launch_bounds__(256) void k_remap_inplace(uint8_t* __restrict__ img, int W, int H, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t per = (size_t)W * H;
+    for (; i < total; i += stride) {
+        const size_t p = i % per;
+        const int y = (int)(p / W), x = (int)(p % W);
+        if (y >= 1 && x >= 1) {
+            uint8_t v = img[i];
+            if (v == 1) img[i] = 255; else if (v == 255) img[i] = 0;
+        }
+    }
+}
+
+void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+    const int span = (int)floor((TW - 1) / g.sca) + 2;            // bound on centre(X0+31) - centre(X0) + 1
+    const int IWmax = span + 2 * g.tapR + 1;
+    const int IWp = (IWmax + 3) & ~3;
+    const int IHmax = IWmax;
+    const int hSize = 2 * g.tapR + 1;
+    const size_t lds = (size_t)IHmax * TW * sizeof(double) + 3 * hSize * sizeof(double) + (size_t)IHmax * IWp;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    dim3 grid((g.w + TW - 1) / TW, (g.h + TH - 1) / TH, n);
+    hipLaunchKernelGGL(k_gauss, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.sca, g.tapR,
+                       IWp, IHmax);
+}
+
+void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+    if (!b.in_rw) return;
+    const size_t total = (size_t)n * g.W * g.H;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_remap_inplace, dim3(blocks), dim3(256), 0, s, b.in_rw, g.W, g.H, total);
+}
+
+}  // namespace lsdhip

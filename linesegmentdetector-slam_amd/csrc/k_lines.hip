@@ -1,0 +1,72 @@
+// k_lines.hip -- K5: accepted rectangles -> structLinesInfo records + lineIm raster (gfx950).
+//
+// Replaces myLSD.cpp:280-368 (and sind/cosd/atand, LSD/baseFunc.cpp:6-16).  One workgroup per image,
+// one wavefront per line (strided); lanes walk the samples of the longer axis.  lineIm has been
+// cleared by a memset node on the same stream; marking 255 is idempotent so store order is free.
+#include "lsd_internal.h"
+
+namespace lsdhip {
+
+__global__ __launch_bounds__(256) void k_lines(const double* __restrict__ recs_scaled, const int32_t* __restrict__ counts,
+                                               lsd_line* __restrict__ lines, uint8_t* __restrict__ line_im,
+                                               int max_lines, int W, int H) {
+    const size_t img = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int n = counts[img];
+    if (n > max_lines) n = max_lines;
+    const double* rs = recs_scaled + img * (size_t)max_lines * 4;
+    lsd_line* out = lines + img * (size_t)max_lines;
+    uint8_t* im = line_im ? line_im + img * (size_t)W * H : nullptr;
+
+    for (int i = wave; i < n; i += 4) {
+        const double x1 = rs[i * 4 + 0], y1 = rs[i * 4 + 1], x2 = rs[i * 4 + 2], y2 = rs[i * 4 + 3];
+        const double k = (y2 - y1) / (x2 - x1);                                    // :289
+        double ang = atan(k) * 180.0 / kPi;                                        // atand, baseFunc.cpp:14-16
+        int orient = 1;
+        if (ang < 0) { ang += 180; orient = -1; }                                  // :292-295
+        int xLow, xHigh, yLow, yHigh;
+        if (x1 > x2) { xLow = cvt_x86(floor(x2)); xHigh = cvt_x86(ceil(x1)); }     // :298-305
+        else         { xLow = cvt_x86(floor(x1)); xHigh = cvt_x86(ceil(x2)); }
+        if (y1 > y2) { yLow = cvt_x86(floor(y2)); yHigh = cvt_x86(ceil(y1)); }     // :306-313
+        else         { yLow = cvt_x86(floor(y1)); yHigh = cvt_x86(ceil(y2)); }
+        const double xRang = fabs(x2 - x1), yRang = fabs(y2 - y1);
+        const int xx_len = xHigh - xLow + 1, yy_len = yHigh - yLow + 1;
+        if (im) {
+            // Q10: only the sampled part of the reference's marking loop is defined behaviour
+            if (xRang > yRang) {                                                   // :319-330
+                for (int j = lane; j < xx_len; j += 64) {
+                    const int xx = j + xLow;
+                    const int yy = cvt_x86(round((xx - x1) * k + y1));
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    if (xx != 0 && yy != 0) im[(size_t)yy * W + xx] = 255;        // :346
+                }
+            } else {                                                               // :331-342
+                for (int j = lane; j < yy_len; j += 64) {
+                    const int yy = j + yLow;
+                    const int xx = cvt_x86(round((yy - y1) / k + x1));
+                    if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                    if (xx != 0 && yy != 0) im[(size_t)yy * W + xx] = 255;        // :352
+                }
+            }
+        }
+        if (lane == 0) {
+            lsd_line L;
+            L.k = k;
+            L.b = (y1 + y2) / 2.0 - k * (x1 + x2) / 2.0;                           // :359
+            L.dx = cos(ang / 180.0 * kPi);                                         // cosd
+            L.dy = sin(ang / 180.0 * kPi);                                         // sind
+            L.x1 = x1; L.y1 = y1; L.x2 = x2; L.y2 = y2;
+            const double ey = y2 - y1, ex = x2 - x1;
+            L.len = sqrt(ey * ey + ex * ex);                                       // :366
+            L.orient = orient;
+            out[i] = L;
+        }
+    }
+}
+
+void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_lines, dim3(n), dim3(256), 0, s, b.recs_scaled, b.counts, b.lines, b.line_im, b.max_lines,
+                       g.W, g.H);
+}
+
+}  // namespace lsdhip

@@ -1,0 +1,602 @@
+// k_region.hip -- K4: the serial region stage, one wavefront (64 lanes) per image (gfx950).
+//
+// Replaces the seed loop of myLineSegmentDetector (LSD/myLSD.cpp:219-272) and its callees
+// RegionGrower (:491-590), CenterGetter/OrientationGetter/RectangleConverter (:592-734),
+// RegionRadiusReducer (:736-802), Refiner (:804-880), LogGammaCalculator (:882-924),
+// RectangleNFACalculator (:926-1059) and RectangleImprover (:1061-1158).
+//
+// The reference semantics are strictly sequential (each seed sees the usedMap left by all earlier
+// ones; inside a region every accepted pixel changes the angle used to test the next), so one image
+// is walked by ONE wavefront and the batch supplies the parallelism (one workgroup per image).
+// Inside the wavefront the lanes cooperate where the order of evaluation can be kept:
+//   * region growing: 8 frontier pixels x 8 neighbours are fetched and angle-tested by 64 lanes,
+//     a ballot gives the first passing candidate in reference order, which is committed, the
+//     region angle is updated and the remaining lanes are re-tested (exactly the reference order);
+//   * rectangle moments: products per lane, SERIAL accumulation in list order (bit-exact sums);
+//   * NFA pixel count: the rectangle's columns are flattened with a wave prefix sum and counted
+//     with ballot/popcount;
+//   * usedMap marking: only the region's pixels are visited (the reference scans the whole image).
+// curMap is a stamp in the upper 30 bits of the per-pixel state word (no per-call clearing).
+#include "lsd_internal.h"
+
+namespace lsdhip {
+
+constexpr int LCAP = 1024;  // region-list entries kept in LDS; the rest spills to HBM
+
+struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
+    double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
+    int pk;
+};
+
+struct RCtx {
+    int w, h, lane;
+    const double* mag;
+    const double* deg;
+    uint32_t* state;
+    uint32_t* spill;
+    uint32_t* gcopy;
+    uint32_t* lst;       // LDS
+    int* s_incl;         // LDS [64]
+    int* s_lo;           // LDS [64]
+    int* s_x;            // LDS [64]
+    uint32_t cur_id;
+    int gnum;            // size of the last grow (grow order)
+    bool has_copy;       // gcopy holds the grow-order list (RegionRadiusReducer reordered lst)
+    double logNT;
+    const double* lgamma;
+    const double* ptab;
+    long long st_grow, st_grown, st_nfa, st_rrr, st_rrrpass, st_sent, st_oob, st_spill;
+};
+
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+__device__ __forceinline__ double rl(double v, int l) {  // broadcast lane l (l wave-uniform)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t pack_xy(int x, int y) { return ((uint32_t)y << 16) | (uint32_t)x; }
+__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? c.lst[i] : c.spill[i - LCAP]; }
+__device__ __forceinline__ void lset(const RCtx& c, int i, uint32_t v) {
+    if (i < LCAP) c.lst[i] = v; else c.spill[i - LCAP] = v;
+}
+__device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp:540-542 / :1009-1011
+    double d = fabs(a - b);
+    if (d > kPi * 3 / 2.0) d = fabs(d - 2.0 * kPi);
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order), returns num and angle.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double tol, int& out_num,
+                                  double& out_deg) {
+    const int lane = c.lane, w = c.w, h = c.h;
+    const uint32_t id = ++c.cur_id;                          // fresh curMap (:519)
+    if (lane == 0) {
+        lset(c, 0, pack_xy(sx, sy));
+        const size_t q = (size_t)sy * w + sx;
+        c.state[q] = (id << 2) | (c.state[q] & 3u);          // :520
+    }
+    double sinS = sin(regDeg), cosS = cos(regDeg);           // :515-516
+    int n = 1;
+    wg_fence();
+    const int e = lane >> 3, k = lane & 7;
+    const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
+    const int ox = kk % 3 - 1, oy = kk / 3 - 1;
+    int ex;
+    do {                                                     // :525 sweeps to fixpoint (Q7)
+        ex = n;
+        for (int i = 0; i < n;) {                            // n is live (:529)
+            const int cnt = min(8, n - i);
+            const bool valid = e < cnt;
+            const uint32_t pk = valid ? lget(c, i + e) : 0u;
+            const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+            const bool inb = valid && nx >= 0 && ny >= 0 && nx < w && ny < h;      // :536
+            const int q = ny * w + nx;
+            const uint32_t word = inb ? c.state[q] : 0u;
+            const bool cand = inb && (word >> 2) != id && (word & 3u) != 1u;       // :537 (2 is growable, Q5)
+            const double d = cand ? c.deg[q] : 0.0;
+            unsigned long long rem = __ballot(cand);
+            bool have_sc = false;
+            double sd = 0, cd = 0;
+            while (rem) {
+                const double dif = angle_diff(regDeg, d);                         // :540-542
+                const unsigned long long pass = __ballot(cand && dif < tol) & rem; // :543
+                if (!pass) break;
+                const int l = __builtin_ctzll(pass);          // first passing candidate in reference order
+                if (!have_sc) {
+                    if ((rem >> lane) & 1ull) { sd = sin(d); cd = cos(d); }
+                    have_sc = true;
+                }
+                cosS += rl(cd, l);                            // :545
+                sinS += rl(sd, l);                            // :546
+                regDeg = atan2(sinS, cosS);                   // :547
+                const int ql = __builtin_amdgcn_readlane(q, l);
+                if (lane == l) {
+                    c.state[q] = (id << 2) | (word & 3u);     // :549
+                    lset(c, n, pack_xy(nx, ny));              // :551-556
+                }
+                n++;
+                rem &= ~((2ull << l) - 1ull);                 // everything up to l has had its turn
+                rem &= ~__ballot(q == ql);                    // the same pixel seen from another frontier pixel
+            }
+            wg_fence();
+            i += cnt;
+        }
+    } while (n != ex);
+    c.gnum = n;
+    c.has_copy = false;
+    c.st_grow++;
+    c.st_grown += n;
+    if (n > LCAP) c.st_spill++;
+    out_num = n;
+    out_deg = regDeg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CenterGetter (:592-619) + OrientationGetter (:621-667) + RectangleConverter (:669-734)
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
+                                          Rec& r) {
+    const int lane = c.lane, w = c.w;
+    double cenX = 0, cenY = 0, ws = 0;
+    for (int base = 0; base < num; base += 64) {                                   // :608-613
+        const int kx = base + lane;
+        const bool valid = kx < num;
+        const uint32_t pkx = valid ? lget(c, kx) : 0u;
+        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+        const double wgt = valid ? c.mag[(size_t)y * w + x] : 0.0;
+        const double ax = wgt * x, ay = wgt * y;
+        const int cnt = min(64, num - base);
+        for (int j = 0; j < cnt; j++) {          // serial accumulation in list order (bit-exact)
+            cenX += rl(ax, j);
+            cenY += rl(ay, j);
+            ws += rl(wgt, j);
+        }
+    }
+    cenX = cenX / ws;
+    cenY = cenY / ws;
+
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    ws = 0;
+    for (int base = 0; base < num; base += 64) {                                   // :637-643
+        const int kx = base + lane;
+        const bool valid = kx < num;
+        const uint32_t pkx = valid ? lget(c, kx) : 0u;
+        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+        const double wgt = valid ? c.mag[(size_t)y * w + x] : 0.0;
+        const double ddy = y - cenY, ddx = x - cenX;
+        const double a = wgt * (ddy * ddy), b = wgt * (ddx * ddx), cc = wgt * ddx * ddy;
+        const int cnt = min(64, num - base);
+        for (int j = 0; j < cnt; j++) {
+            Ixx += rl(a, j);
+            Iyy += rl(b, j);
+            Ixy -= rl(cc, j);
+            ws += rl(wgt, j);
+        }
+    }
+    Ixx /= ws; Iyy /= ws; Ixy /= ws;
+    const double dI = Ixx - Iyy;
+    const double lamb = (Ixx + Iyy - sqrt(dI * dI + 4 * Ixy * Ixy)) / 2.0;          // :647
+    double inertiaDeg;
+    if (fabs(Ixx) > fabs(Iyy)) inertiaDeg = atan2(lamb - Ixx, Ixy);               // :649-652
+    else inertiaDeg = atan2(Ixy, lamb - Iyy);
+    double regDif = inertiaDeg - regdeg;                                          // :655-665
+    while (regDif <= -kPi) regDif += 2 * kPi;
+    while (regDif > kPi) regDif -= 2 * kPi;
+    if (regDif < 0) regDif = -regDif;
+    if (regDif > tol) inertiaDeg += kPi;
+
+    const double dx = cos(inertiaDeg), dy = sin(inertiaDeg);                       // :699-700
+    double lenMin = 0, lenMax = 0, widMin = 0, widMax = 0;                         // Q9: start at 0 (:701)
+    for (int base = 0; base < num; base += 64) {
+        const int kx = base + lane;
+        if (kx < num) {
+            const uint32_t pkx = lget(c, kx);
+            const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+            const double len = (x - cenX) * dx + (y - cenY) * dy;                  // :704
+            const double wid = -(x - cenX) * dy + (y - cenY) * dx;                 // :705
+            lenMin = fmin(lenMin, len); lenMax = fmax(lenMax, len);
+            widMin = fmin(widMin, wid); widMax = fmax(widMax, wid);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {   // min/max are order-independent: plain wave reduction
+        lenMin = fmin(lenMin, __shfl_xor(lenMin, off));
+        lenMax = fmax(lenMax, __shfl_xor(lenMax, off));
+        widMin = fmin(widMin, __shfl_xor(widMin, off));
+        widMax = fmax(widMax, __shfl_xor(widMax, off));
+    }
+    r.x1 = cenX + lenMin * dx; r.y1 = cenY + lenMin * dy;                          // :717-720
+    r.x2 = cenX + lenMax * dx; r.y2 = cenY + lenMax * dy;
+    r.wid = widMax - widMin;
+    r.cX = cenX; r.cY = cenY; r.deg = inertiaDeg; r.dx = dx; r.dy = dy;
+    r.p = aliPro; r.prec = tol; r.pk = pk;
+    if (r.wid < 1) r.wid = 1;                                                      // :730
+}
+
+__device__ __forceinline__ double rec_density(int num, const Rec& r) {             // :757,:798,:827,:867
+    const double ex = r.x1 - r.x2, ey = r.y1 - r.y2;
+    return num / (sqrt(ex * ex + ey * ey) * r.wid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RegionRadiusReducer, myLSD.cpp:736-802 (incl. the `i <= num` sentinel behaviour)
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
+                                           double denThre) {
+    const int lane = c.lane, w = c.w;
+    c.st_rrr++;
+    double den = rec_density(num, rec);
+    if (den > denThre) return true;                                                // :760
+    // keep the grow-order list for the marking loops before it gets reordered
+    for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
+    c.has_copy = true;
+    wg_fence();
+    const double ax = sx - rec.x1, ay = sy - rec.y1, bx = sx - rec.x2, by = sy - rec.y2;
+    const double rad1 = sqrt(ax * ax + ay * ay), rad2 = sqrt(bx * bx + by * by);    // :768-769
+    double rad = rad1 > rad2 ? rad1 : rad2;
+    bool removed_any = false;
+    while (den < denThre) {                                                        // :775
+        rad *= 0.75;
+        c.st_rrrpass++;
+        int i = 0;
+        while (i <= num) {                                                         // :779 (`<=`)
+            int px, py;
+            if (i == num) {
+                if (!removed_any) { c.st_oob++; break; }   // the reference reads out of bounds here (UB): no removal
+                px = 0; py = 0;                            // slot holds the NULL written at :784-785
+            } else {
+                const uint32_t pkx = lget(c, i);
+                px = (int)(pkx & 0xffffu); py = (int)(pkx >> 16);
+            }
+            const double ddx = sx - px, ddy = sy - py;
+            if (sqrt(ddx * ddx + ddy * ddy) > rad) {                               // :780
+                if (lane == 0) {
+                    const size_t q = (size_t)py * w + px;
+                    c.state[q] = c.state[q] & 3u;                                  // curMap = 0 (:781)
+                    if (i == num) { lset(c, num - 1, 0u); }
+                    else { lset(c, i, lget(c, num - 1)); lset(c, num - 1, 0u); }   // :782-785
+                }
+                if (i == num) c.st_sent++;
+                wg_fence();
+                removed_any = true;
+                i--;
+                num--;
+            }
+            i++;
+        }
+        if (num < 2) return false;                                                 // :792
+        rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec, rec);                // :797
+        den = rec_density(num, rec);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LogGammaCalculator (:882-924): integers below kLgTable come from the host-computed table
+// ---------------------------------------------------------------------------------------------
+__device__ double log_gamma_dev(const RCtx& c, int x) {
+    if (x >= 0 && x < kLgTable) return c.lgamma[x];
+    const double xd = x;
+    return 0.918938533204673 + (xd - 0.5) * log(xd) - xd +
+           0.5 * xd * log(xd * sinh(1.0 / xd) + 1.0 / (810 * pow(xd, 6.0)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ double rect_nfa(RCtx& c, const Rec& rec) {
+    const int lane = c.lane, xLim = c.w, yLim = c.h;
+    const double logNT = c.logNT;
+    c.st_nfa++;
+    double verX[4], verY[4];
+    verX[0] = rec.x1 - rec.dy * rec.wid / 2.0;                                     // :949-956
+    verX[1] = rec.x2 - rec.dy * rec.wid / 2.0;
+    verX[2] = rec.x2 + rec.dy * rec.wid / 2.0;
+    verX[3] = rec.x1 + rec.dy * rec.wid / 2.0;
+    verY[0] = rec.y1 + rec.dx * rec.wid / 2.0;
+    verY[1] = rec.y2 + rec.dx * rec.wid / 2.0;
+    verY[2] = rec.y2 - rec.dx * rec.wid / 2.0;
+    verY[3] = rec.y1 - rec.dx * rec.wid / 2.0;
+    int offset;
+    if ((rec.x1 < rec.x2) && (rec.y1 <= rec.y2)) offset = 0;                       // :959-966
+    else if ((rec.x1 >= rec.x2) && (rec.y1 < rec.y2)) offset = 1;
+    else if ((rec.x1 > rec.x2) && (rec.y1 >= rec.y2)) offset = 2;
+    else offset = 3;
+    const double vx0 = verX[offset & 3], vx1 = verX[(offset + 1) & 3], vx2 = verX[(offset + 2) & 3],
+                 vx3 = verX[(offset + 3) & 3];
+    const double vy0 = verY[offset & 3], vy1 = verY[(offset + 1) & 3], vy2 = verY[(offset + 2) & 3],
+                 vy3 = verY[(offset + 3) & 3];
+    const double cx0 = ceil(vx0);
+    int xlen = cvt_x86(cx0 - floor(vx2));                                          // :973
+    if (xlen < 0 && xlen != (int)0x80000000) xlen = -xlen;
+    xlen = (int)((unsigned)xlen + 1u);
+    const double k0 = (vy1 - vy0) / (vx1 - vx0);                                   // :979-982
+    const double k1 = (vy2 - vy1) / (vx2 - vx1);
+    const double k2 = (vy2 - vy3) / (vx2 - vx3);
+    const double k3 = (vy3 - vy0) / (vx3 - vx0);
+    int all = 0, ali = 0;
+    for (int cb = 0; cb < xlen; cb += 64) {
+        const int i = cb + lane;
+        int cntc = 0, lo = 0, xr = 0;
+        if (i < xlen) {
+            xr = cvt_x86(i + cx0);                                                 // :976
+            int yLow, yHigh;
+            if (xr < vx3) yLow = cvt_x86(ceil(vy0 + (xr - vx0) * k3));             // :988-989
+            else          yLow = cvt_x86(ceil(vy3 + (xr - vx3) * k2));             // :992-993
+            if (xr < vx1) yHigh = cvt_x86(floor(vy0 + (xr - vx0) * k0));           // :998-999
+            else          yHigh = cvt_x86(floor(vy1 + (xr - vx1) * k1));           // :1002-1003
+            if (xr >= 0 && xr < xLim) {                                            // :1007
+                lo = yLow < 0 ? 0 : yLow;
+                const int hi = yHigh > yLim - 1 ? yLim - 1 : yHigh;
+                if (hi >= lo) cntc = hi - lo + 1;
+            }
+        }
+        int inc = cntc;                                       // inclusive wave scan of the column heights
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        const int tot = __builtin_amdgcn_readlane(inc, 63);
+        if (tot == 0) continue;
+        c.s_incl[lane] = inc; c.s_lo[lane] = lo; c.s_x[lane] = xr;
+        wg_fence();
+        all += tot;
+        for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
+            const int t = t0 + lane;
+            bool hit = false;
+            if (t < tot) {
+                int ci = 0;                                    // smallest ci with s_incl[ci] > t
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (c.s_incl[ci + step - 1] <= t) ci += step;
+                const int ex = ci ? c.s_incl[ci - 1] : 0;
+                const int j = c.s_lo[ci] + (t - ex);
+                const double dv = c.deg[(size_t)j * xLim + c.s_x[ci]];
+                hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
+            }
+            ali += __builtin_popcountll(__ballot(hit));
+        }
+        wg_fence();
+    }
+    if (all == 0 || ali == 0) return -logNT;                                       // :1019-1022
+    const double logp = c.ptab[rec.pk * 3 + 0], log10p = c.ptab[rec.pk * 3 + 1], log1mp = c.ptab[rec.pk * 3 + 2];
+    if (all == ali) return -logNT - all * log10p;                                  // :1023-1026
+    const double proTerm = rec.p / (1.0 - rec.p);
+    const double log1Coef = log_gamma_dev(c, all + 1) - log_gamma_dev(c, ali + 1) - log_gamma_dev(c, all - ali + 1);
+    const double log1Term = log1Coef + ali * logp + (all - ali) * log1mp;          // :1033
+    double term = exp(log1Term);
+    const double eps = 2.2204e-16;
+    if (fabs(term) < 100 * eps) {                                                  // :1037-1043
+        if (ali > all * rec.p) return -log10(term) - logNT;
+        return -logNT;
+    }
+    double binTail = term;
+    const double tole = 0.1;
+    for (int i = ali + 1; i <= all; i++) {                                         // :1046-1056
+        const double binTerm = (all - i + 1) / (i * 1.0);
+        const double multTerm = binTerm * proTerm;
+        term *= multTerm;
+        binTail += term;
+        if (binTerm < 1) {
+            const double err = term * ((1 - pow(multTerm, (double)(all - i + 1))) / (1.0 - multTerm) - 1);
+            if (err < tole * fabs(-log10(binTail) - logNT) * binTail) break;
+        }
+    }
+    return -log10(binTail) - logNT;
+}
+
+// RectangleImprover, myLSD.cpp:1061-1158
+__device__ __noinline__ double improve(RCtx& c, Rec& rec_io) {
+    const double delt = 0.5, delt2 = delt / 2.0;
+    Rec best = rec_io;
+    double bestNFA = rect_nfa(c, best);
+    if (bestNFA > 0) return bestNFA;                                               // :1078
+    Rec r = best;
+    for (int i = 0; i < 5; i++) {                                                  // :1084-1092
+        r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
+        const double v = rect_nfa(c, r);
+        if (v > bestNFA) { bestNFA = v; best = r; }
+    }
+    if (bestNFA > 0) { rec_io = best; return bestNFA; }
+    r = best;
+    for (int i = 0; i < 5; i++) {                                                  // :1097-1107
+        if (r.wid - delt >= 0.5) {
+            r.wid -= delt;
+            const double v = rect_nfa(c, r);
+            if (v > bestNFA) { bestNFA = v; best = r; }
+        }
+    }
+    if (bestNFA > 0) { rec_io = best; return bestNFA; }
+    r = best;
+    for (int i = 0; i < 5; i++) {                                                  // :1112-1125
+        if (r.wid - delt >= 0.5) {
+            r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2;
+            r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2;
+            r.wid -= delt;
+            const double v = rect_nfa(c, r);
+            if (v > bestNFA) { bestNFA = v; best = r; }
+        }
+    }
+    if (bestNFA > 0) { rec_io = best; return bestNFA; }
+    r = best;
+    for (int i = 0; i < 5; i++) {                                                  // :1130-1143
+        if (r.wid - delt >= 0.5) {
+            r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2;
+            r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2;
+            r.wid -= delt;
+            const double v = rect_nfa(c, r);
+            if (v > bestNFA) { bestNFA = v; best = r; }
+        }
+    }
+    if (bestNFA > 0) { rec_io = best; return bestNFA; }
+    r = best;
+    for (int i = 0; i < 5; i++) {                                                  // :1148-1156
+        r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
+        const double v = rect_nfa(c, r);
+        if (v > bestNFA) { bestNFA = v; best = r; }
+    }
+    rec_io = best;
+    return bestNFA;
+}
+
+// Refiner, myLSD.cpp:804-880
+__device__ __noinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& regdeg, Rec& rec, double denThre) {
+    const int lane = c.lane, w = c.w;
+    double den = rec_density(num, rec);
+    if (den >= denThre) return true;                                               // :829
+    const double cenDeg = c.deg[(size_t)sy * w + sx];
+    double difSum = 0, squSum = 0;
+    int ptNum = 0;
+    for (int base = 0; base < num; base += 64) {                                   // :839-853
+        const int kx = base + lane;
+        bool flag = false;
+        double degDif = 0;
+        if (kx < num) {
+            const uint32_t pkx = lget(c, kx);
+            const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+            const double ddx = sx - x, ddy = sy - y;
+            if (sqrt(ddx * ddx + ddy * ddy) < rec.wid) {
+                flag = true;
+                degDif = c.deg[(size_t)y * w + x] - cenDeg;
+                while (degDif <= -kPi) degDif += 2 * kPi;
+                while (degDif > kPi) degDif -= 2 * kPi;
+            }
+        }
+        const double sq = degDif * degDif;
+        unsigned long long m = __ballot(flag);
+        while (m) {                               // serial accumulation in list order
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            difSum += rl(degDif, j);
+            squSum += rl(sq, j);
+            ptNum++;
+        }
+    }
+    const double meanDif = difSum / (ptNum * 1.0);
+    const double tol2 = 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
+    grow(c, sx, sy, cenDeg, tol2, num, regdeg);                                    // :857
+    if (num < 2) return false;                                                     // :861
+    rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec, rec);                    // :866
+    den = rec_density(num, rec);
+    if (den < denThre) return radius_reduce(c, sx, sy, num, regdeg, rec, denThre); // :869-877
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// seed loop, myLSD.cpp:219-272
+// ---------------------------------------------------------------------------------------------
+__device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 restricted to the grown pixels
+    const int w = c.w;
+    for (int k2 = c.lane; k2 < c.gnum; k2 += 64) {
+        const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
+        const size_t q = (size_t)(pkx >> 16) * w + (pkx & 0xffffu);
+        const uint32_t word = c.state[q];
+        if ((word >> 2) == c.cur_id) c.state[q] = (word & ~3u) | val;   // curMap == 1 only
+    }
+    wg_fence();
+}
+
+__global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
+    __shared__ uint32_t lst[LCAP];
+    __shared__ int s_incl[64], s_lo[64], s_x[64];
+    const size_t img = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int w = g.w, h = g.h;
+    const size_t npx = (size_t)g.npx;
+
+    RCtx c;
+    c.w = w; c.h = h; c.lane = lane;
+    c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.state = b.state + img * npx;
+    c.spill = b.spill + img * npx; c.gcopy = b.gcopy + img * npx;
+    c.lst = lst; c.s_incl = s_incl; c.s_lo = s_lo; c.s_x = s_x;
+    c.cur_id = 0; c.gnum = 0; c.has_copy = false;
+    c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
+    c.st_grow = c.st_grown = c.st_nfa = c.st_rrr = c.st_rrrpass = c.st_sent = c.st_oob = c.st_spill = 0;
+
+    const uint32_t* ord = b.ord + img * npx;
+    const int nb = b.nb[img];
+    double* recs = b.recs + img * (size_t)b.max_lines * 12;
+    double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
+    SeedRec* trace = b.seeds ? reinterpret_cast<SeedRec*>(b.seeds) + img * npx : nullptr;
+    int ntrace = 0, cntLines = 0;
+    int epoch = 0;
+
+    for (int base = 0; base < nb; base += 64) {
+        const int idx = base + lane;
+        const uint32_t p = idx < nb ? ord[idx] : 0u;
+        const uint32_t wd0 = idx < nb ? c.state[p] : 1u;
+        unsigned long long m = __ballot(idx < nb && (wd0 & 3u) == 0u);               // :222
+        const int epoch0 = epoch;
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, l);
+            if (epoch != epoch0) {                      // a region was marked since the chunk was loaded
+                const uint32_t wd = c.state[pp];
+                if ((wd & 3u) != 0u) continue;
+            }
+            const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
+            int num; double regdeg;
+            grow(c, sx, sy, c.deg[pp], g.degThre, num, regdeg);                       // :225
+            SeedRec tr;
+            tr.order_idx = base + l; tr.x = sx; tr.y = sy; tr.num = num; tr.outcome = 0; tr.final_num = num;
+            tr.logNFA = 0;
+            bool done = false;
+            Rec rec;
+            if (num < g.regThre) done = true;                                        // :228 (not marked, Q5)
+            if (!done) {
+                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232
+                const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);      // :234
+                tr.final_num = num;
+                if (!ok) { tr.outcome = 1; done = true; }                            // :237
+            }
+            if (!done) {
+                const double logNFA = improve(c, rec);                               // :240
+                tr.logNFA = logNFA;
+                if (logNFA <= 0) {                                                   // :242-250
+                    mark_region(c, 2u);
+                    epoch++;
+                    tr.outcome = 2;
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (cntLines < b.max_lines && lane == 0) {
+                    double* rr = recs + (size_t)cntLines * 12;
+                    rr[0] = rec.x1; rr[1] = rec.y1; rr[2] = rec.x2; rr[3] = rec.y2; rr[4] = rec.wid; rr[5] = rec.cX;
+                    rr[6] = rec.cY; rr[7] = rec.deg; rr[8] = rec.dx; rr[9] = rec.dy; rr[10] = rec.p; rr[11] = rec.prec;
+                    double x1 = rec.x1, y1 = rec.y1, x2 = rec.x2, y2 = rec.y2;
+                    if (g.sca != 1) {                                                // :252-258
+                        x1 = (x1 - 1.0) / g.sca + 1; y1 = (y1 - 1.0) / g.sca + 1;
+                        x2 = (x2 - 1.0) / g.sca + 1; y2 = (y2 - 1.0) / g.sca + 1;
+                    }
+                    double* rs = recs_scaled + (size_t)cntLines * 4;
+                    rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
+                }
+                cntLines++;
+                mark_region(c, 1u);                                                  // :259-265
+                epoch++;
+                tr.outcome = 3;
+            }
+            if (trace && lane == 0) trace[ntrace] = tr;
+            ntrace++;
+        }
+    }
+    if (lane == 0) {
+        b.counts[img] = cntLines;
+        if (b.nseed) b.nseed[img] = ntrace;
+        if (b.stats) {
+            long long* st = b.stats + img * 8;
+            st[0] = c.st_grow; st[1] = c.st_grown; st[2] = c.st_nfa; st[3] = c.st_rrr; st[4] = c.st_rrrpass;
+            st[5] = c.st_sent; st[6] = c.st_oob; st[7] = c.st_spill;
+        }
+    }
+}
+
+void launch_region(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_region, dim3(n), dim3(64), 0, s, g, b);
+}
+
+}  // namespace lsdhip

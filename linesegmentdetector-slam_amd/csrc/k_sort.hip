@@ -1,0 +1,115 @@
+// k_sort.hip -- K3: pseudo-ordering of the gradient (bin + compact + stable descending sort), gfx950.
+//
+// Replaces myLSD.cpp:177-204: zoom = pseBin/maxGrad, v = floor(mag*zoom) clipped to pseBin, keep
+// v != 0 in raster order, then qsort(binCell, Comp).  glibc's qsort is a stable merge sort and the
+// comparator never returns 0, so the reference order is "descending v, raster order among ties"
+// (SURVEY 8a-Q4).  Here that order is produced directly by a stable counting sort:
+//
+//   one 1024-thread workgroup per image; wave s owns the s-th contiguous raster segment;
+//   pass 1  per-wave LDS histograms hist[s][pseBin - v]                     (LDS atomics)
+//   scan    start[s][b] = sum_{b'<b} tot[b'] + sum_{s'<s} hist[s'][b]        (block prefix sum)
+//   pass 2  each wave re-streams its segment 64 pixels at a time; lanes that share a bin get
+//           consecutive ranks in lane (= raster) order via ballot + popcount, no global atomics.
+//
+// The result is deterministic and independent of wave scheduling.
+#include "lsd_internal.h"
+
+namespace lsdhip {
+
+constexpr int SNT = 1024, SWAVES = SNT / 64;
+
+__device__ __forceinline__ int bin_of(double m, double zoom, int pseBin) {
+    int v = cvt_x86(floor(m * zoom));                              // myLSD.cpp:182
+    if (v > pseBin) v = pseBin;                                    // :183-184
+    return (int)(uint16_t)v;                                       // pseIdx is CV_16UC1 (:178,:187)
+}
+
+__global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
+                                              const unsigned long long* __restrict__ maxbits,
+                                              uint32_t* __restrict__ ord, uint16_t* __restrict__ ordv,
+                                              int32_t* __restrict__ nb, int npx, int pseBin) {
+    extern __shared__ uint32_t hist[];                             // [SWAVES][pseBin] then [SWAVES] scratch
+    uint32_t* wsum = hist + SWAVES * pseBin;
+    const size_t img = blockIdx.x;
+    const double* m = mag + img * (size_t)npx;
+    uint32_t* o = ord + img * (size_t)npx;
+    uint16_t* ov = ordv + img * (size_t)npx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    const double maxGrad = __longlong_as_double((long long)maxbits[img]);
+    if (!(maxGrad > 0)) {                                          // blank image: reference reads garbage; define as empty
+        if (tid == 0) nb[img] = 0;
+        return;
+    }
+    const double zoom = 1.0 * pseBin / maxGrad;                    // :179
+    const int segLen = ((npx + SNT - 1) / SNT) * 64;
+    const int beg = min(wave * segLen, npx), end = min(beg + segLen, npx);
+
+    for (int i = tid; i < SWAVES * pseBin; i += SNT) hist[i] = 0;
+    __syncthreads();
+
+    uint32_t* myh = hist + wave * pseBin;
+    for (int base = beg; base < end; base += 64) {
+        const int p = base + lane;
+        const int v = p < end ? bin_of(m[p], zoom, pseBin) : 0;
+        if (v != 0) atomicAdd(&myh[pseBin - v], 1u);
+    }
+    __syncthreads();
+
+    // exclusive scan over bins (descending value == ascending b), then over waves inside a bin
+    {
+        uint32_t tot = 0;
+        if (tid < pseBin)
+            for (int s = 0; s < SWAVES; s++) tot += hist[s * pseBin + tid];
+        uint32_t inc = tot;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int s = 0; s < wave; s++) wbase += wsum[s];
+        uint32_t run = wbase + inc - tot;
+        if (tid < pseBin)
+            for (int s = 0; s < SWAVES; s++) {
+                const uint32_t c = hist[s * pseBin + tid];
+                hist[s * pseBin + tid] = run;
+                run += c;
+            }
+        if (tid == SNT - 1) nb[img] = (int32_t)(wbase + inc);     // total (bins >= pseBin contribute 0)
+    }
+    __syncthreads();
+
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = beg; base < end; base += 64) {
+        const int p = base + lane;
+        const int v = p < end ? bin_of(m[p], zoom, pseBin) : 0;
+        const int b = pseBin - v;
+        unsigned long long act = __ballot(v != 0);
+        while (act) {
+            const int l = __builtin_ctzll(act);
+            const int bsel = __builtin_amdgcn_readlane(b, l);
+            const bool mine = (v != 0) && (b == bsel);
+            const unsigned long long mm = __ballot(mine);
+            const uint32_t start = myh[bsel];
+            if (mine) {
+                const uint32_t r = start + (uint32_t)__builtin_popcountll(mm & lt);
+                o[r] = (uint32_t)p;
+                ov[r] = (uint16_t)v;
+            }
+            if (lane == l) myh[bsel] = start + (uint32_t)__builtin_popcountll(mm);
+            act &= ~mm;
+        }
+    }
+}
+
+void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+    const size_t lds = ((size_t)SWAVES * g.pseBin + SWAVES) * sizeof(uint32_t);
+    // 16 x 1024 bins x 4 B is just over the 64 KiB default; gfx950 has 160 KiB of LDS per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(SNT), lds, s, b.mag, b.maxbits, b.ord, b.ordv, b.nb, g.npx, g.pseBin);
+}
+
+}  // namespace lsdhip

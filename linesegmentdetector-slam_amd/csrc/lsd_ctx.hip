@@ -1,0 +1,462 @@
+// lsd_ctx.hip -- host side of liblsdhip.so: context, HBM workspace, host-computed tables, launch
+// sequencing and the C ABI declared in include/lsd_hip.h.
+//
+// Everything numerical on the hot path runs in the HIP kernels (k_*.hip).  The host computes only
+// what the reference also computes once per call on scalars: the Gaussian taps (myLSD.cpp:398-417),
+// the thresholds (myLSD.cpp:148-149, :207-209) and two small lookup tables (log-gamma of integers,
+// logs of p = aliPro/2^k) that the kernels index instead of evaluating libm on the device.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "lsd_internal.h"
+
+using namespace lsdhip;
+
+struct lsd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // the context's own stream
+    hipStream_t last_stream = nullptr; // stream of the last enqueue
+    std::string err;
+    // workspace capacity
+    size_t cap_n = 0, cap_npx = 0, cap_wh = 0;
+    int cap_max_lines = 0;
+    bool cap_trace = false;
+    // workspace
+    double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
+    uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr;
+    uint16_t* ordv = nullptr;
+    unsigned long long* maxbits = nullptr;
+    int32_t *nb = nullptr, *nseed = nullptr;
+    long long* stats = nullptr;
+    void* seeds = nullptr;
+    // host-API staging
+    uint8_t *h_in = nullptr, *h_lineim = nullptr;
+    lsd_line* h_lines = nullptr;
+    int32_t* h_counts = nullptr;
+    size_t hcap_n = 0, hcap_wh = 0;
+    int hcap_max_lines = 0;
+    bool hcap_lineim = false;
+    // tables
+    double *d_taps = nullptr, *d_lgamma = nullptr, *d_ptab = nullptr;
+    lsd_params tab_params{};
+    bool tab_valid = false;
+    int tapR = 0;
+    // options
+    int stop_after = 0;
+    bool trace = false;
+    int host_max_lines = 8192;
+    // last run
+    Geom geom{};
+    int last_n = 0;
+    int last_max_lines = 0;
+    int32_t* last_counts = nullptr;
+    hipEvent_t ev[7]{};
+    bool ev_valid = false;
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return LSD_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// host-computed scalars and tables
+// ---------------------------------------------------------------------------------------------
+static int tap_radius(double sca, double sig) {                     // myLSD.cpp:390-393
+    const int prec = 3;
+    if (sca < 1) sig = sig / sca;
+    return cvt_x86(ceil(sig * sqrt(2 * prec * log(10))));
+}
+
+static void gauss_taps(double sca, double sig, int h, std::vector<double>& t) {   // myLSD.cpp:398-417
+    if (sca < 1) sig = sig / sca;
+    const int hSize = 1 + 2 * h;
+    t.assign((size_t)3 * hSize, 0.0);
+    double s1 = 0, s2 = 0, s3 = 0;
+    for (int k = 0; k < hSize; k++) {
+        const double a = (k - h) / sig, b = (k - h - 1.0 / 3) / sig, c = (k - h + 1.0 / 3) / sig;
+        t[0 * hSize + k] = exp(-0.5 * (a * a));
+        t[1 * hSize + k] = exp(-0.5 * (b * b));
+        t[2 * hSize + k] = exp(-0.5 * (c * c));
+        s1 += t[0 * hSize + k]; s2 += t[1 * hSize + k]; s3 += t[2 * hSize + k];
+    }
+    for (int k = 0; k < hSize; k++) {
+        t[0 * hSize + k] /= s1; t[1 * hSize + k] /= s2; t[2 * hSize + k] /= s3;
+    }
+}
+
+static double log_gamma_host(int x) {                               // LogGammaCalculator, myLSD.cpp:882-924
+    if (x > 15)
+        return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1.0 / x) + 1.0 / (810 * pow(x, 6)));
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705,
+                                1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), b = 0;
+    for (int i = 0; i < 7; i++) { a -= log(x + i); b += q[i] * pow(x, i); }
+    return a + log(b);
+}
+
+static int make_geom(const lsd_params* p, int cols, int rows, Geom* g) {
+    if (!p || cols <= 0 || rows <= 0) return LSD_ERR_INVALID;
+    if (!(p->sca > 0) || !(p->sig > 0) || !(p->angThre > 0) || p->pseBin < 1) return LSD_ERR_INVALID;
+    if (p->pseBin > 1024) return LSD_ERR_UNSUPPORTED;
+    if (cols > 65535 || rows > 65535) return LSD_ERR_UNSUPPORTED;   // region lists pack (y<<16 | x)
+    g->W = cols; g->H = rows;
+    g->w = cvt_x86(floor(cols * p->sca));                           // myLSD.cpp:132
+    g->h = cvt_x86(floor(rows * p->sca));                           // :133
+    if (g->w < 2 || g->h < 2) return LSD_ERR_INVALID;
+    if ((long long)g->w * g->h > (1ll << 30)) return LSD_ERR_UNSUPPORTED;
+    g->npx = g->w * g->h;
+    g->sca = p->sca;
+    g->tapR = tap_radius(p->sca, p->sig);
+    if (g->tapR < 0 || g->tapR > kMaxTapRadius) return LSD_ERR_UNSUPPORTED;
+    g->pseBin = p->pseBin;
+    g->degThre = p->angThre / 180.0 * kPi;                          // :148
+    g->gradThre = 2.0 / sin(g->degThre);                            // :149
+    g->logNT = 5 * (log10(g->h) + log10(g->w)) / 2.0;               // :207
+    g->regThre = -g->logNT / log10(p->angThre / 180.0);             // :208
+    g->aliPro = p->angThre / 180.0;                                 // :209
+    g->denThre = p->denThre;
+    return LSD_OK;
+}
+
+static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStream_t s) {
+    if (c->tab_valid && memcmp(&c->tab_params, p, sizeof(lsd_params)) == 0) return LSD_OK;
+    if (!c->d_lgamma) {
+        std::vector<double> lg(kLgTable);
+        for (int i = 0; i < kLgTable; i++) lg[i] = i >= 1 ? log_gamma_host(i) : 0.0;
+        HIPCHK(c, hipMalloc(&c->d_lgamma, sizeof(double) * kLgTable));
+        HIPCHK(c, hipMemcpy(c->d_lgamma, lg.data(), sizeof(double) * kLgTable, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_ptab, sizeof(double) * kPTable * 3));
+        HIPCHK(c, hipMalloc(&c->d_taps, sizeof(double) * 3 * (2 * kMaxTapRadius + 1)));
+    }
+    std::vector<double> taps;
+    gauss_taps(p->sca, p->sig, g.tapR, taps);
+    double pt[kPTable * 3];
+    double pr = g.aliPro;
+    for (int k = 0; k < kPTable; k++) {
+        pt[k * 3 + 0] = log(pr); pt[k * 3 + 1] = log10(pr); pt[k * 3 + 2] = log(1 - pr);   // myLSD.cpp:1024,:1033
+        pr /= 2.0;                                                                          // :1085,:1149
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(c->d_taps, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_ptab, pt, sizeof(pt), hipMemcpyHostToDevice));
+    c->tab_params = *p;
+    c->tab_valid = true;
+    c->tapR = g.tapR;
+    return LSD_OK;
+}
+
+template <class T>
+static hipError_t re_alloc(T** p, size_t count) {
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)p, count * sizeof(T));
+}
+
+static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
+    const bool grow_main = n > c->cap_n || npx > c->cap_npx;
+    if (grow_main) {
+        const size_t nn = n > c->cap_n ? n : c->cap_n, pp = npx > c->cap_npx ? npx : c->cap_npx;
+        HIPCHK(c, hipDeviceSynchronize());
+        const size_t tot = nn * pp;
+        HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
+        HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
+        HIPCHK(c, re_alloc(&c->spill, tot)); HIPCHK(c, re_alloc(&c->gcopy, tot));
+        HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
+        HIPCHK(c, re_alloc(&c->stats, nn * 8));
+        if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
+        if (nn != c->cap_n) { c->cap_max_lines = 0; }
+        c->cap_n = nn; c->cap_npx = pp;
+    }
+    if (max_lines > c->cap_max_lines) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->recs, c->cap_n * (size_t)max_lines * 12));
+        HIPCHK(c, re_alloc(&c->recs_scaled, c->cap_n * (size_t)max_lines * 4));
+        c->cap_max_lines = max_lines;
+    }
+    if (trace && !c->cap_trace) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMalloc(&c->seeds, c->cap_n * c->cap_npx * sizeof(SeedRec)));
+        c->cap_trace = true;
+    }
+    (void)wh;
+    return LSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int lsd_abi_version(void) { return LSD_ABI_VERSION; }
+
+const char* lsd_strerror(int st) {
+    switch (st) {
+        case LSD_OK: return "ok";
+        case LSD_ERR_INVALID: return "invalid argument";
+        case LSD_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case LSD_ERR_HIP: return "HIP runtime error";
+        case LSD_ERR_UNSUPPORTED: return "parameter outside the implemented range";
+        case LSD_ERR_CAPACITY: return "line capacity exceeded";
+        case LSD_ERR_NOMEM: return "out of host memory";
+        default: return "unknown status";
+    }
+}
+
+void lsd_default_params(lsd_params* p) {                            // LSD/baseFunc.h:64-68
+    if (!p) return;
+    p->sca = 0.3; p->sig = 0.6; p->angThre = 22.5; p->denThre = 0.7; p->pseBin = 1024;
+}
+
+void lsd_scaled_size(int cols, int rows, double sca, int* w, int* h) {
+    if (w) *w = cvt_x86(floor(cols * sca));
+    if (h) *h = cvt_x86(floor(rows * sca));
+}
+
+int lsd_create(lsd_ctx** out, int device) {
+    if (!out) return LSD_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LSD_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return LSD_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LSD_ERR_NO_DEVICE;
+    lsd_ctx* c = new (std::nothrow) lsd_ctx();
+    if (!c) return LSD_ERR_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LSD_ERR_HIP; }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return LSD_ERR_HIP; }
+    c->last_stream = c->stream;
+    *out = c;
+    return LSD_OK;
+}
+
+void lsd_destroy(lsd_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->ordv,
+                    c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
+                    c->d_taps, c->d_lgamma, c->d_ptab};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* lsd_last_error(const lsd_ctx* c) { return c ? c->err.c_str() : ""; }
+void lsd_free(void* p) { free(p); }
+
+int lsd_set_stop_after(lsd_ctx* c, int stage) {
+    if (!c || stage < 0 || stage > LSD_STAGE_REGION) return LSD_ERR_INVALID;
+    c->stop_after = stage;
+    return LSD_OK;
+}
+int lsd_set_trace(lsd_ctx* c, int on) {
+    if (!c) return LSD_ERR_INVALID;
+    c->trace = on != 0;
+    return LSD_OK;
+}
+
+int lsd_reserve(lsd_ctx* c, int n, int cols, int rows) {
+    if (!c || n <= 0) return LSD_ERR_INVALID;
+    lsd_params p; lsd_default_params(&p);
+    Geom g;
+    int st = make_geom(&p, cols, rows, &g);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipSetDevice(c->device));
+    return ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)cols * rows, c->cap_max_lines, c->trace);
+}
+
+int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int rows, const lsd_params* p,
+                             unsigned flags, uint8_t* d_line_ims, lsd_line* d_lines, int max_lines, int32_t* d_counts,
+                             void* stream) {
+    if (!c || !d_maps || n <= 0 || !d_lines || !d_counts || max_lines <= 0) return LSD_ERR_INVALID;
+    Geom g;
+    int st = make_geom(p, cols, rows, &g);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    st = ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)cols * rows, max_lines, c->trace);
+    if (st != LSD_OK) return st;
+    st = ensure_tables(c, p, g, s);
+    if (st != LSD_OK) return st;
+
+    Buffers b{};
+    b.in = d_maps;
+    b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
+    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy;
+    b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
+    b.max_lines = max_lines;
+    b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
+    b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
+
+    HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));
+    HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, s));
+    HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * n, s));
+    if (d_line_ims) HIPCHK(c, hipMemsetAsync(d_line_ims, 0, (size_t)n * cols * rows, s));   // Mat::zeros, myLSD.cpp:215
+
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    launch_gauss(g, b, n, s);
+    if (b.in_rw) launch_remap_writeback(g, b, n, s);
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_GRAD) launch_gradient(g, b, n, s);
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) launch_sort(g, b, n, s);
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) launch_region(g, b, n, s);
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    if (c->stop_after == 0) launch_lines(g, b, n, s);
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipGetLastError());
+    c->ev_valid = true;
+    c->geom = g; c->last_n = n; c->last_max_lines = max_lines; c->last_counts = d_counts; c->last_stream = s;
+    return LSD_OK;
+}
+
+int lsd_synchronize(lsd_ctx* c) {
+    if (!c) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    return LSD_OK;
+}
+
+int lsd_last_timings(lsd_ctx* c, float ms[6]) {
+    if (!c || !ms || !c->ev_valid) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev[5]));
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    return LSD_OK;
+}
+
+static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, bool lineim) {
+    if (n > c->hcap_n || wh > c->hcap_wh || max_lines > c->hcap_max_lines || (lineim && !c->hcap_lineim)) {
+        const size_t nn = n > c->hcap_n ? n : c->hcap_n, ww = wh > c->hcap_wh ? wh : c->hcap_wh;
+        const int ml = max_lines > c->hcap_max_lines ? max_lines : c->hcap_max_lines;
+        const bool li = lineim || c->hcap_lineim;
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->h_in, nn * ww));
+        HIPCHK(c, re_alloc(&c->h_lineim, li ? nn * ww : 0));
+        HIPCHK(c, re_alloc(&c->h_lines, nn * (size_t)ml));
+        HIPCHK(c, re_alloc(&c->h_counts, nn));
+        c->hcap_n = nn; c->hcap_wh = ww; c->hcap_max_lines = ml; c->hcap_lineim = li;
+    }
+    return LSD_OK;
+}
+
+int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const lsd_params* p, uint8_t* line_ims,
+                  lsd_line** lines_out, int* offsets_out) {
+    if (!c || !maps || n <= 0 || !lines_out || !offsets_out) return LSD_ERR_INVALID;
+    *lines_out = nullptr;
+    Geom g;
+    int st = make_geom(p, cols, rows, &g);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t wh = (size_t)cols * rows;
+    const int ml = c->host_max_lines;
+    st = ensure_host_staging(c, (size_t)n, wh, ml, line_ims != nullptr);
+    if (st != LSD_OK) return st;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->h_in, maps, (size_t)n * wh, hipMemcpyHostToDevice, s));
+    st = lsd_enqueue_batch_device(c, c->h_in, n, cols, rows, p, LSD_FLAG_WRITEBACK_MAP, line_ims ? c->h_lineim : nullptr,
+                                  c->h_lines, ml, c->h_counts, s);
+    if (st != LSD_OK) return st;
+    std::vector<int32_t> counts(n);
+    HIPCHK(c, hipMemcpyAsync(counts.data(), c->h_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(maps, c->h_in, (size_t)n * wh, hipMemcpyDeviceToHost, s));      // observable in-place remap
+    if (line_ims) HIPCHK(c, hipMemcpyAsync(line_ims, c->h_lineim, (size_t)n * wh, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int total = 0, status = LSD_OK;
+    offsets_out[0] = 0;
+    for (int i = 0; i < n; i++) {
+        int k = counts[i];
+        if (k > ml) { k = ml; status = LSD_ERR_CAPACITY; }
+        total += k;
+        offsets_out[i + 1] = total;
+    }
+    lsd_line* out = (lsd_line*)calloc(total > 0 ? total : 1, sizeof(lsd_line));
+    if (!out) return LSD_ERR_NOMEM;
+    for (int i = 0; i < n; i++) {
+        const int k = offsets_out[i + 1] - offsets_out[i];
+        if (k > 0)
+            HIPCHK(c, hipMemcpy(out + offsets_out[i], c->h_lines + (size_t)i * ml, sizeof(lsd_line) * k,
+                                hipMemcpyDeviceToHost));
+    }
+    *lines_out = out;
+    return status;
+}
+
+int lsd_run(lsd_ctx* c, uint8_t* map, int cols, int rows, size_t stride, const lsd_params* p, uint8_t* line_im,
+            size_t line_im_stride, lsd_line** lines_out, int* n_lines) {
+    if (!c || !map || !lines_out || !n_lines || cols <= 0 || rows <= 0) return LSD_ERR_INVALID;
+    if (stride < (size_t)cols || (line_im && line_im_stride < (size_t)cols)) return LSD_ERR_INVALID;
+    *n_lines = 0;
+    const bool packed = stride == (size_t)cols && (!line_im || line_im_stride == (size_t)cols);
+    int offs[2] = {0, 0};
+    if (packed) {
+        int st = lsd_run_batch(c, map, 1, cols, rows, p, line_im, lines_out, offs);
+        *n_lines = offs[1];
+        return st;
+    }
+    std::vector<uint8_t> tmp((size_t)cols * rows), tim(line_im ? (size_t)cols * rows : 0);
+    for (int y = 0; y < rows; y++) memcpy(&tmp[(size_t)y * cols], map + (size_t)y * stride, cols);
+    int st = lsd_run_batch(c, tmp.data(), 1, cols, rows, p, line_im ? tim.data() : nullptr, lines_out, offs);
+    for (int y = 0; y < rows; y++) memcpy(map + (size_t)y * stride, &tmp[(size_t)y * cols], cols);
+    if (line_im)
+        for (int y = 0; y < rows; y++) memcpy(line_im + (size_t)y * line_im_stride, &tim[(size_t)y * cols], cols);
+    *n_lines = offs[1];
+    return st;
+}
+
+int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
+    if (!c || !out || image < 0 || image >= c->last_n) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    const size_t npx = (size_t)c->geom.npx, off = (size_t)image * npx;
+    const void* src = nullptr;
+    size_t need = 0;
+    int32_t nbv = 0, cnt = 0, nseed = 0;
+    switch (what) {
+        case LSD_DBG_GAUSS: src = c->gauss + off; need = npx * 8; break;
+        case LSD_DBG_MAG: src = c->mag + off; need = npx * 8; break;
+        case LSD_DBG_DEG: src = c->deg + off; need = npx * 8; break;
+        case LSD_DBG_STATE: src = c->state + off; need = npx * 4; break;
+        case LSD_DBG_ORDER:
+        case LSD_DBG_ORDER_VAL:
+            HIPCHK(c, hipMemcpy(&nbv, c->nb + image, 4, hipMemcpyDeviceToHost));
+            if (what == LSD_DBG_ORDER) { src = c->ord + off; need = (size_t)nbv * 4; }
+            else { src = c->ordv + off; need = (size_t)nbv * 2; }
+            break;
+        case LSD_DBG_NB: src = c->nb + image; need = 4; break;
+        case LSD_DBG_MAXGRAD: src = c->maxbits + image; need = 8; break;
+        case LSD_DBG_RECS:
+            HIPCHK(c, hipMemcpy(&cnt, c->last_counts + image, 4, hipMemcpyDeviceToHost));
+            if (cnt > c->last_max_lines) cnt = c->last_max_lines;
+            src = c->recs + (size_t)image * c->last_max_lines * 12; need = (size_t)cnt * 12 * 8;
+            break;
+        case LSD_DBG_NSEED: src = c->nseed + image; need = 4; break;
+        case LSD_DBG_SEEDS:
+            if (!c->seeds) return LSD_ERR_INVALID;
+            HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
+            src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
+            break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * 8; need = 64; break;
+        default: return LSD_ERR_INVALID;
+    }
+    if (bytes < need) return LSD_ERR_INVALID;
+    if (need) HIPCHK(c, hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    return LSD_OK;
+}
+
+}  // extern "C"

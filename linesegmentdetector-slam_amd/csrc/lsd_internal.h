@@ -1,0 +1,81 @@
+// lsd_internal.h -- shared between the host side (lsd_ctx.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lsd_hip.h"
+
+namespace lsdhip {
+
+constexpr double kPi = 3.14159265358979323846;  // == 4.0*atan(1.0), myLSD.cpp:9
+constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per phase kernel
+constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries
+constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
+
+// Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
+// host libm so that they are the very numbers the reference computes (myLSD.cpp:132-133,148-149,207-209).
+struct Geom {
+    int W, H;            // original size
+    int w, h;            // scaled size
+    int npx;             // w*h
+    double sca;
+    int tapR;            // Gaussian tap radius h (myLSD.cpp:393)
+    int pseBin;
+    double degThre;      // angThre/180*pi
+    double gradThre;     // 2/sin(degThre)
+    double logNT;        // 5*(log10(h)+log10(w))/2
+    double regThre;      // -logNT/log10(angThre/180)
+    double aliPro;       // angThre/180
+    double denThre;
+};
+
+// Per-batch device buffers (image i lives at base + i*stride of each array).
+struct Buffers {
+    const uint8_t* in;     // n x H x W (pitch W)
+    uint8_t* in_rw;        // same pointer when write-back of the remap is requested, else null
+    double* gauss;         // n x npx
+    double* mag;           // n x npx
+    double* deg;           // n x npx
+    uint32_t* state;       // n x npx : (curMap stamp << 2) | usedMap value
+    unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
+    int32_t* nb;           // n : sorted-list length
+    uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
+    uint16_t* ordv;        // n x npx : bin values
+    uint32_t* spill;       // n x npx : region list beyond the LDS part
+    uint32_t* gcopy;       // n x npx : grow-order copy used when RegionRadiusReducer reorders the list
+    double* recs;          // n x max_lines x 12 (structRec before rescale)
+    double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
+    int32_t* counts;       // n
+    lsd_line* lines;       // n x max_lines
+    uint8_t* line_im;      // n x H x W or null
+    int max_lines;
+    // tables
+    const double* taps;    // 3 x (2*tapR+1)
+    const double* lgamma;  // kLgTable
+    const double* ptab;    // kPTable x 3 : log(p), log10(p), log(1-p)
+    // debug
+    void* seeds;           // n x npx trace records or null
+    int32_t* nseed;        // n
+    long long* stats;      // n x 8
+};
+
+struct SeedRec {  // mirrors oracle's orc_seed
+    int order_idx, x, y, num, outcome, final_num;
+    double logNFA;
+};
+
+// launchers (each enqueues on `s`)
+void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_region(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
+
+// x86-64 cvttsd2si semantics of the reference's (int) casts: NaN, +-inf and
+// out-of-range values give INT_MIN.  v_cvt_i32_f64 would give 0 / saturate instead.
+__host__ __device__ inline int cvt_x86(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+}  // namespace lsdhip

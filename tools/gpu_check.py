@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Stage-by-stage comparison of the HIP path with the CPU oracle (developer tool, run on the GPU box)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+
+def ulps(a, b):
+    ai = a.view(np.int64); bi = b.view(np.int64)
+    return np.abs(ai - bi)
+
+def check(name, img, ctx, verbose=True):
+    ref = oracle.lsd(img.copy(), debug=True)
+    d = ref["dbg"]
+    w, h = d["w"], d["h"]
+    m = img.copy()
+    ctx.set_trace(True)
+    t = time.time()
+    lines, line_im = ctx.run(m)
+    dt = time.time() - t
+    ok = True
+    g = ctx.fetch(0, lsd.DBG_GAUSS, (w, h)); mg = ctx.fetch(0, lsd.DBG_MAG, (w, h)); dg = ctx.fetch(0, lsd.DBG_DEG, (w, h))
+    st = ctx.fetch(0, lsd.DBG_STATE, (w, h)); used = (st & 3).astype(np.uint8)
+    order = ctx.fetch(0, lsd.DBG_ORDER, (w, h)); ov = ctx.fetch(0, lsd.DBG_ORDER_VAL, (w, h))
+    res = {}
+    res["gauss_exact"] = bool(np.array_equal(g, d["gauss"]))
+    res["mag_exact"] = bool(np.array_equal(mg, d["mag"]))
+    du = ulps(dg, d["deg"]); res["deg_maxulp"] = int(du.max()); res["deg_ndiff"] = int((du > 0).sum())
+    res["maxgrad_exact"] = ctx.fetch(0, lsd.DBG_MAXGRAD, (w, h)) == d["maxGrad"]
+    res["nb"] = (len(order), d["nb"])
+    oo = d["ord_y"].astype(np.int64) * w + d["ord_x"]
+    res["order_exact"] = len(order) == d["nb"] and bool(np.array_equal(order.astype(np.int64), oo)) and bool(np.array_equal(ov, d["ord_v"]))
+    res["used_exact"] = bool(np.array_equal(used, d["used"])); res["used_ndiff"] = int((used != d["used"]).sum())
+    res["nlines"] = (len(lines), len(ref["lines"]))
+    res["map_inplace"] = bool(np.array_equal(m, oracle_map(img)))
+    res["lineim_exact"] = bool(np.array_equal(line_im, ref["lineIm"])); res["lineim_ndiff"] = int((line_im != ref["lineIm"]).sum())
+    if len(lines) == len(ref["lines"]) and len(lines):
+        err = 0.0
+        for f in ("x1", "y1", "x2", "y2", "len", "dx", "dy", "b"):
+            err = max(err, float(np.abs(lines[f] - ref["lines"][f]).max()))
+        res["line_maxabs"] = err
+        res["orient_eq"] = bool(np.array_equal(lines["orient"], ref["lines"]["orient"]))
+    seeds = ctx.fetch(0, lsd.DBG_SEEDS, (w, h))
+    rs = d["seeds"]
+    res["nseed"] = (len(seeds), len(rs))
+    if len(seeds) == len(rs):
+        for f in ("order_idx", "x", "y", "num", "outcome", "final_num"):
+            if not np.array_equal(seeds[f], rs[f]):
+                bad = np.nonzero(seeds[f] != rs[f])[0][:5]
+                res["seed_" + f] = [(int(i), int(seeds[f][i]), int(rs[f][i])) for i in bad]
+        res["logNFA_maxabs"] = float(np.abs(seeds["logNFA"] - rs["logNFA"]).max())
+    else:
+        k = min(len(seeds), len(rs))
+        for f in ("order_idx", "num", "outcome", "final_num"):
+            bad = np.nonzero(seeds[f][:k] != rs[f][:k])[0][:5]
+            if len(bad): res["seed_" + f] = [(int(i), int(seeds[f][i]), int(rs[f][i])) for i in bad]
+    res["stats"] = ctx.fetch(0, lsd.DBG_STATS, (w, h))
+    res["timings_ms"] = {k: round(v, 3) for k, v in ctx.timings().items()}
+    res["host_ms"] = round(dt * 1e3, 2)
+    print(name, img.shape, res, flush=True)
+    return res
+
+def oracle_map(img):
+    m = img.copy(); oracle.lsd(m, want_lineim=False); return m
+
+if __name__ == "__main__":
+    z = np.load(os.path.join(ROOT, "tests/golden/maps.npz"))
+    ctx = lsd.Context(0)
+    names = sys.argv[1:] or ["map1", "mapValue", "aisle1", "aisle2", "aisle3", "f3key", "f4key"]
+    for n in names:
+        if n == "tile2048":
+            img = np.ascontiguousarray(np.tile(z["aisle1"], (4, 2))[:2048, :2048])
+        else:
+            img = z[n]
+        check(n, img, ctx)
