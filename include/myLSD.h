@@ -1,0 +1,139 @@
+/*
+ * myLSD.h -- C++ adapter with the reference's own names on top of the C ABI (lsd_hip.h).
+ *
+ * Gives host C++ code the call boundary of the reference's LSD/myLSD.h:
+ *     mylsd::structLSD mylsd::myLineSegmentDetector(Mat MapGray, int oriMapCol, int oriMapRow,
+ *             double sca, double sig, double angThre, double denThre, int pseBin);   (LSD/myLSD.h:132)
+ * with the same argument meaning, the same in-place rewrite of MapGray (LSD/myLSD.cpp:135-142), the
+ * same structLSD{lineIm, linesInfo, len_linesInfo} result (LSD/myLSD.h:123-127; linesInfo is malloc'ed
+ * and owned by the caller exactly like the reference's), plus mylsd::runLSD -- the name BASELINE.json
+ * uses; the reference has no such symbol, it is an alias with the baseFunc.h defaults.
+ *
+ * Image type: cv::Mat when OpenCV is available (define LSD_WITH_OPENCV or let __has_include find it),
+ * otherwise the small ref-counted lsd::Image<T> below (same ptr<T>(row)/rows/cols/zeros surface).
+ * Errors: the reference has no error handling (it would crash); the adapter throws mylsd::lsd_error
+ * carrying the C-ABI status.  There is no CPU fallback behind this header.
+ */
+#ifndef LSD_MYLSD_ADAPTER_H
+#define LSD_MYLSD_ADAPTER_H
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "lsd_hip.h"
+
+#if !defined(LSD_WITH_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#define LSD_WITH_OPENCV 1
+#endif
+#endif
+#ifdef LSD_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+/* structLinesInfo, LSD/baseFunc.h:33-44 (skipped when the reference's baseFunc.h was included first) */
+#ifndef _BASEFUNC_
+typedef struct _structLinesInfo {
+    double k, b, dx, dy, x1, y1, x2, y2, len;
+    int orient;
+} structLinesInfo;
+/* LSD defaults, LSD/baseFunc.h:64-68 */
+static const double lsd_sca = 0.3, lsd_sig = 0.6, lsd_angThre = 22.5, lsd_denThre = 0.7;
+static const int pseBin = 1024;
+#endif
+static_assert(sizeof(structLinesInfo) == sizeof(lsd_line), "structLinesInfo must be layout-identical to lsd_line");
+
+namespace lsd {
+/* Minimal ref-counted row-major image (shallow copies share pixels, like cv::Mat). */
+template <class T>
+class Image {
+public:
+    int rows = 0, cols = 0;
+    size_t step = 0; /* bytes per row */
+    Image() = default;
+    static Image zeros(int r, int c) {
+        Image m;
+        m.rows = r; m.cols = c; m.step = sizeof(T) * (size_t)c;
+        m.buf_.reset(static_cast<unsigned char*>(std::calloc((size_t)r * m.step + 16, 1)), std::free);
+        m.data = m.buf_.get();
+        return m;
+    }
+    template <class U> U* ptr(int row) { return reinterpret_cast<U*>(data + (size_t)row * step); }
+    template <class U> const U* ptr(int row) const { return reinterpret_cast<const U*>(data + (size_t)row * step); }
+    void release() { buf_.reset(); data = nullptr; rows = cols = 0; }
+    unsigned char* data = nullptr;
+private:
+    std::shared_ptr<unsigned char> buf_;
+};
+}  // namespace lsd
+
+namespace mylsd {
+
+#ifdef LSD_WITH_OPENCV
+typedef cv::Mat Mat;
+inline Mat make_u8(int rows, int cols) { return cv::Mat::zeros(rows, cols, CV_8UC1); }
+#else
+typedef lsd::Image<unsigned char> Mat;
+inline Mat make_u8(int rows, int cols) { return Mat::zeros(rows, cols); }
+#endif
+
+struct lsd_error : std::runtime_error {
+    int status;
+    lsd_error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+typedef struct _structLSD { /* LSD/myLSD.h:123-127 */
+    Mat lineIm;
+    structLinesInfo* linesInfo;
+    int len_linesInfo;
+} structLSD;
+
+/* process-wide context on device LSD_DEVICE (default 0), created on first use */
+inline lsd_ctx* context() {
+    struct Holder {
+        lsd_ctx* c = nullptr;
+        int st = LSD_OK;
+        Holder() {
+            const char* d = std::getenv("LSD_DEVICE");
+            st = lsd_create(&c, d ? std::atoi(d) : 0);
+        }
+        ~Holder() { if (c) lsd_destroy(c); }
+    };
+    static Holder h;
+    if (h.st != LSD_OK) throw lsd_error(h.st, lsd_strerror(h.st));
+    return h.c;
+}
+
+inline structLSD myLineSegmentDetector(Mat MapGray, int oriMapCol, int oriMapRow, double sca, double sig,
+                                       double angThre, double denThre, int pseBin_) {
+    lsd_ctx* c = context();
+    lsd_params p;
+    p.sca = sca; p.sig = sig; p.angThre = angThre; p.denThre = denThre; p.pseBin = pseBin_;
+    structLSD r;
+    r.lineIm = make_u8(oriMapRow, oriMapCol);
+    lsd_line* lines = nullptr;
+    int n = 0;
+    const int st = lsd_run(c, MapGray.template ptr<unsigned char>(0), oriMapCol, oriMapRow, (size_t)MapGray.step,
+                           &p, r.lineIm.template ptr<unsigned char>(0), (size_t)r.lineIm.step, &lines, &n);
+    if (st != LSD_OK) {
+        lsd_free(lines);
+        throw lsd_error(st, std::string(lsd_strerror(st)) + ": " + lsd_last_error(c));
+    }
+    r.linesInfo = reinterpret_cast<structLinesInfo*>(lines); /* malloc'ed; the caller owns it */
+    r.len_linesInfo = n;
+    return r;
+}
+
+/* north_star's name for the same call, with the LSD/baseFunc.h:64-68 defaults */
+inline structLSD runLSD(Mat MapGray, double sca = 0.3, double sig = 0.6, double angThre = 22.5,
+                        double denThre = 0.7, int pseBin_ = 1024) {
+    return myLineSegmentDetector(MapGray, MapGray.cols, MapGray.rows, sca, sig, angThre, denThre, pseBin_);
+}
+
+}  // namespace mylsd
+
+#endif /* LSD_MYLSD_ADAPTER_H */

@@ -220,9 +220,10 @@ class Context:
         if what == DBG_ORDER_VAL:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
-            v = get(what, np.int64, 8)
+            v = get(what, np.int64, 16)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                             "rrr_oob_reads", "list_spills"), [int(x) for x in v]))
+                             "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
+                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds"), [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)
             return get(what, SEED_DTYPE, ns)

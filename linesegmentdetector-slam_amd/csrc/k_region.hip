@@ -46,6 +46,7 @@ struct RCtx {
     const double* lgamma;
     const double* ptab;
     long long st_grow, st_grown, st_nfa, st_rrr, st_rrrpass, st_sent, st_oob, st_spill;
+    long long t_grow, t_rect, t_nfa, t_mark, st_maxreg, st_nfapx;   // cycle counters (s_memtime) + extremes
 };
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -73,6 +74,7 @@ __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp
 __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double tol, int& out_num,
                                   double& out_deg) {
     const int lane = c.lane, w = c.w, h = c.h;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     const uint32_t id = ++c.cur_id;                          // fresh curMap (:519)
     if (lane == 0) {
         lset(c, 0, pack_xy(sx, sy));
@@ -131,6 +133,8 @@ __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double
     c.st_grow++;
     c.st_grown += n;
     if (n > LCAP) c.st_spill++;
+    if (n > c.st_maxreg) c.st_maxreg = n;
+    c.t_grow += (long long)__builtin_amdgcn_s_memtime() - t0;
     out_num = n;
     out_deg = regDeg;
 }
@@ -141,6 +145,7 @@ __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double
 __device__ __noinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
                                           Rec& r) {
     const int lane = c.lane, w = c.w;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     double cenX = 0, cenY = 0, ws = 0;
     for (int base = 0; base < num; base += 64) {                                   // :608-613
         const int kx = base + lane;
@@ -214,6 +219,7 @@ __device__ __noinline__ void rect_convert(RCtx& c, int num, double regdeg, doubl
     r.cX = cenX; r.cY = cenY; r.deg = inertiaDeg; r.dx = dx; r.dy = dy;
     r.p = aliPro; r.prec = tol; r.pk = pk;
     if (r.wid < 1) r.wid = 1;                                                      // :730
+    c.t_rect += (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
 __device__ __forceinline__ double rec_density(int num, const Rec& r) {             // :757,:798,:827,:867
@@ -287,7 +293,7 @@ __device__ double log_gamma_dev(const RCtx& c, int x) {
 // ---------------------------------------------------------------------------------------------
 // RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ double rect_nfa(RCtx& c, const Rec& rec) {
+__device__ __noinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
     const int lane = c.lane, xLim = c.w, yLim = c.h;
     const double logNT = c.logNT;
     c.st_nfa++;
@@ -344,6 +350,7 @@ __device__ __noinline__ double rect_nfa(RCtx& c, const Rec& rec) {
         c.s_incl[lane] = inc; c.s_lo[lane] = lo; c.s_x[lane] = xr;
         wg_fence();
         all += tot;
+        c.st_nfapx += tot;
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
             bool hit = false;
@@ -385,6 +392,13 @@ __device__ __noinline__ double rect_nfa(RCtx& c, const Rec& rec) {
         }
     }
     return -log10(binTail) - logNT;
+}
+
+__device__ __forceinline__ double rect_nfa(RCtx& c, const Rec& rec) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    const double v = rect_nfa_impl(c, rec);
+    c.t_nfa += (long long)__builtin_amdgcn_s_memtime() - t0;
+    return v;
 }
 
 // RectangleImprover, myLSD.cpp:1061-1158
@@ -489,6 +503,7 @@ __device__ __noinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& r
 // ---------------------------------------------------------------------------------------------
 __device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 restricted to the grown pixels
     const int w = c.w;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     for (int k2 = c.lane; k2 < c.gnum; k2 += 64) {
         const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
         const size_t q = (size_t)(pkx >> 16) * w + (pkx & 0xffffu);
@@ -496,6 +511,7 @@ __device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 re
         if ((word >> 2) == c.cur_id) c.state[q] = (word & ~3u) | val;   // curMap == 1 only
     }
     wg_fence();
+    c.t_mark += (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
 __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
@@ -514,6 +530,8 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
     c.cur_id = 0; c.gnum = 0; c.has_copy = false;
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
     c.st_grow = c.st_grown = c.st_nfa = c.st_rrr = c.st_rrrpass = c.st_sent = c.st_oob = c.st_spill = 0;
+    c.t_grow = c.t_rect = c.t_nfa = c.t_mark = c.st_maxreg = c.st_nfapx = 0;
+    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
 
     const uint32_t* ord = b.ord + img * npx;
     const int nb = b.nb[img];
@@ -588,9 +606,11 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
         b.counts[img] = cntLines;
         if (b.nseed) b.nseed[img] = ntrace;
         if (b.stats) {
-            long long* st = b.stats + img * 8;
+            long long* st = b.stats + img * 16;
             st[0] = c.st_grow; st[1] = c.st_grown; st[2] = c.st_nfa; st[3] = c.st_rrr; st[4] = c.st_rrrpass;
             st[5] = c.st_sent; st[6] = c.st_oob; st[7] = c.st_spill;
+            st[8] = (long long)__builtin_amdgcn_s_memtime() - t_begin; st[9] = c.t_grow; st[10] = c.t_rect;
+            st[11] = c.t_nfa; st[12] = c.t_mark; st[13] = c.st_maxreg; st[14] = c.st_nfapx; st[15] = ntrace;
         }
     }
 }

@@ -172,7 +172,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         HIPCHK(c, re_alloc(&c->spill, tot)); HIPCHK(c, re_alloc(&c->gcopy, tot));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * 8));
+        HIPCHK(c, re_alloc(&c->stats, nn * 16));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp;
@@ -451,7 +451,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * 8; need = 64; break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * 16; need = 128; break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

@@ -1,0 +1,106 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the shard assignment and the line-list gather
+(linesegmentdetector-slam_amd/dist.py) on synthetic per-rank line buffers, plus the bench's batch generator."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_shard(lo, hi, max_lines):
+    """Deterministic fake results for global images lo..hi-1: image g has (g*7)%5 + (g%3) lines."""
+    n = hi - lo
+    lines = torch.zeros((n, max_lines, 10), dtype=torch.int64)
+    counts = torch.zeros(n, dtype=torch.int32)
+    for j in range(n):
+        g = lo + j
+        c = (g * 7) % 5 + (g % 3)
+        counts[j] = c
+        for k in range(c):
+            lines[j, k] = torch.arange(10, dtype=torch.int64) + 1000 * g + 10 * k
+        lines[j, c:] = -1                                         # garbage beyond the count must never travel
+    return lines, counts
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = ldist.shard_range(n_total, world, rank)
+    lines, counts = _fake_shard(lo, hi, 8)
+    offsets, out = ldist.gather_line_lists(lines, counts, n_total, dst=0)
+    if rank == 0:
+        q.put((offsets.numpy(), out.numpy()))
+    else:
+        assert offsets is None and out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [7, 8, 1])
+def test_gather_line_lists_gloo_world2(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + n_total
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    offsets, out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp_lines, exp_counts = _fake_shard(0, n_total, 8)
+    exp_off = np.concatenate([[0], np.cumsum(exp_counts.numpy())])
+    assert np.array_equal(offsets, exp_off)
+    dense = np.concatenate([exp_lines[g, :exp_counts[g]].numpy() for g in range(n_total)] + [np.zeros((0, 10), np.int64)])
+    assert np.array_equal(out, dense)
+    assert (out >= 0).all()
+
+
+def test_shard_range_partitions():
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    for n in (1, 5, 8, 512, 513):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = ldist.shard_range(n, world, r)
+                assert 0 <= lo <= hi <= n
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+    assert ldist.shard_range(512, 8, 3) == (192, 256)
+
+
+def test_compact_and_numpy_view(lsdmod):
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    rec = np.zeros(3, lsdmod.LINE_DTYPE)
+    rec["x1"] = [1.5, 2.5, 3.5]; rec["k"] = [np.inf, -0.0, np.nan]; rec["orient"] = [1, -1, 1]
+    raw = torch.from_numpy(rec.view(np.int64).reshape(3, 10).copy())
+    lines = torch.zeros((2, 4, 10), dtype=torch.int64)
+    lines[0, :2] = raw[:2]; lines[1, :1] = raw[2:]
+    dense, c = ldist.compact_lines(lines, torch.tensor([2, 1], dtype=torch.int32))
+    back = ldist.lines_to_numpy(dense, lsdmod.LINE_DTYPE)
+    assert back.tobytes() == rec.tobytes()                        # byte-exact, NaN/inf/-0.0 included
+    dense, c = ldist.compact_lines(lines, torch.tensor([9, 0], dtype=torch.int32))   # overflowed image is clamped
+    assert dense.shape[0] == 4 and c.tolist() == [4, 0]
+
+
+def test_bench_batch_generator(maps):
+    sys.path.insert(0, ROOT)
+    import bench
+    b = bench.make_batch(maps, 5, 512)
+    assert b.shape == (5, 512, 512) and b.dtype == np.uint8
+    assert np.array_equal(b[0], np.tile(maps["aisle1"], (1, 1))[:512, :512])     # image 0: unshifted, unflipped aisle1 tile
+    assert np.array_equal(bench.make_image(maps, 3, 512), b[3])                   # seeded: reproducible
+    assert np.array_equal(bench.make_batch(maps, 2, 512, first=3)[0], b[3])       # rank shards see the same images
+    assert set(np.unique(b)) <= {0, 1, 255}
+    flip = bench.make_image(maps, 4, 512)                                         # i//4%4 == 1 -> left-right flip
+    assert not np.array_equal(flip, bench.make_image(maps, 0, 512))

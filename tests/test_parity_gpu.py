@@ -1,0 +1,323 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same inputs, against the committed golden answers, and -- at BASELINE.json's full size -- through
+size-independent properties.
+
+Stated tolerances (north_star: "line-for-line within a stated endpoint/angle tolerance, bit-exact
+UsedMap indexing"):
+  * GaussImage, magMap, maxGrad, sorted seed order, usedMap, lineIm, in-place remap, line count,
+    orient: BIT-EXACT;
+  * degMap: <= 2 ulp (device atan2 vs glibc);
+  * line endpoints x1,y1,x2,y2 and len: 1e-6 px absolute; dx,dy: 1e-9; k,b: 1e-6 relative
+    (transcendentals on the rectangle path differ by ulps between OCML and glibc).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import tile2048
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ["map1", "mapValue", "aisle1", "aisle2", "aisle3", "f3key", "f4key"]
+ENDPOINT_TOL = 1e-6
+DIR_TOL = 1e-9
+REL_TOL = 1e-6
+DEG_ULP = 2
+
+
+@pytest.fixture(scope="module")
+def ctx(lsdmod):
+    c = lsdmod.Context(0)
+    yield c
+    c.close()
+
+
+def ulps(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+def assert_lines_close(got, ref):
+    assert len(got) == len(ref)
+    if not len(ref):
+        return
+    for f in ("x1", "y1", "x2", "y2", "len"):
+        assert np.abs(got[f] - ref[f]).max() <= ENDPOINT_TOL, f
+    for f in ("dx", "dy"):
+        assert np.abs(got[f] - ref[f]).max() <= DIR_TOL, f
+    for f in ("k", "b"):
+        a, b = got[f], ref[f]
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin)
+        assert np.array_equal(a[~fin], b[~fin], equal_nan=True)
+        assert np.all(np.abs(a[fin] - b[fin]) <= REL_TOL * np.maximum(1.0, np.abs(b[fin]))), f
+    assert np.array_equal(got["orient"], ref["orient"])
+
+
+def full_check(lsdmod, ctx, oracle, img, params=None, kw=None):
+    kw = kw or {}
+    ref_map = img.copy()
+    ref = oracle.lsd(ref_map, debug=True, **kw)
+    d = ref["dbg"]
+    w, h = d["w"], d["h"]
+    got_map = img.copy()
+    lines, line_im = ctx.run(got_map, params)
+    assert np.array_equal(got_map, ref_map)                                   # observable in-place remap (Q2)
+    assert np.array_equal(ctx.fetch(0, lsdmod.DBG_GAUSS, (w, h)), d["gauss"])
+    assert np.array_equal(ctx.fetch(0, lsdmod.DBG_MAG, (w, h)), d["mag"])
+    assert ctx.fetch(0, lsdmod.DBG_MAXGRAD, (w, h)) == d["maxGrad"]
+    assert ulps(ctx.fetch(0, lsdmod.DBG_DEG, (w, h)), d["deg"]).max() <= DEG_ULP
+    order = ctx.fetch(0, lsdmod.DBG_ORDER, (w, h)).astype(np.int64)
+    assert len(order) == d["nb"]
+    assert np.array_equal(order, d["ord_y"].astype(np.int64) * w + d["ord_x"])
+    assert np.array_equal(ctx.fetch(0, lsdmod.DBG_ORDER_VAL, (w, h)), d["ord_v"])
+    used = (ctx.fetch(0, lsdmod.DBG_STATE, (w, h)) & 3).astype(np.uint8)
+    assert np.array_equal(used, d["used"])                                     # bit-exact UsedMap
+    assert np.array_equal(line_im, ref["lineIm"])
+    assert_lines_close(lines, ref["lines"])
+    st = ctx.fetch(0, lsdmod.DBG_STATS, (w, h))
+    for k in ("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops", "rrr_oob_reads"):
+        assert st[k] == d[k], k
+    return lines, line_im, ref
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_parity(name, maps, lsdmod, ctx, oracle):
+    full_check(lsdmod, ctx, oracle, maps[name])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fixture_known_answers(name, maps, known, lsdmod, ctx):
+    """The HIP path against the reference's recorded outputs directly (no oracle in the loop)."""
+    nl, lit = known["counts"][name][:2]
+    lines, line_im = ctx.run(maps[name].copy())
+    assert len(lines) == nl
+    assert int((line_im == 255).sum()) == lit
+
+
+def test_map1_golden_line_list(maps, known, lsdmod, ctx):
+    lines, _ = ctx.run(maps["map1"].copy())
+    gold = known["map1_lines"]
+    assert len(lines) == len(gold)
+    for got, row in zip(lines, gold):
+        for f, s in zip(known["map1_lines_fields"], row):
+            if f == "orient":
+                assert int(got[f]) == int(s)
+            elif f in ("k", "b"):
+                assert abs(got[f] - float(s)) <= REL_TOL * max(1.0, abs(float(s)))
+            elif f in ("dx", "dy"):
+                assert abs(got[f] - float(s)) <= DIR_TOL
+            else:
+                assert abs(got[f] - float(s)) <= ENDPOINT_TOL
+
+
+def test_tile2048_parity_and_known(maps, known, lsdmod, ctx, oracle):
+    img = tile2048(maps["aisle1"])
+    lines, line_im, _ = full_check(lsdmod, ctx, oracle, img)
+    assert len(lines) == known["counts"]["tile2048"][0]
+    assert int((line_im == 255).sum()) == known["counts"]["tile2048"][1]
+
+
+def test_seed_trace_matches_oracle(maps, lsdmod, ctx, oracle):
+    """Every seed makes the same decision (small / refine-failed / NFA-rejected / accepted) with the same region sizes."""
+    img = maps["f4key"]
+    ref = oracle.lsd(img.copy(), debug=True)["dbg"]
+    ctx.set_trace(True)
+    try:
+        ctx.run(img.copy())
+        seeds = ctx.fetch(0, lsdmod.DBG_SEEDS, (ref["w"], ref["h"]))
+    finally:
+        ctx.set_trace(False)
+    rs = ref["seeds"]
+    assert len(seeds) == len(rs)
+    for f in ("order_idx", "x", "y", "num", "outcome", "final_num"):
+        assert np.array_equal(seeds[f], rs[f]), f
+    acc = rs["outcome"] == 3
+    assert np.all(np.abs(seeds["logNFA"][acc] - rs["logNFA"][acc]) <= 0.11 * np.abs(rs["logNFA"][acc]) + 1e-9)
+
+
+def test_reference_names(maps, lsdmod, ctx, oracle):
+    """myLineSegmentDetector / runLSD / structLSD as the reference spells them (LSD/myLSD.h:123-132)."""
+    img = maps["map1"]
+    m = img.copy()
+    r = lsdmod.myLineSegmentDetector(m, img.shape[1], img.shape[0], lsdmod.lsd_sca, lsdmod.lsd_sig, lsdmod.lsd_angThre,
+                                     lsdmod.lsd_denThre, lsdmod.pseBin, ctx=ctx)
+    assert r.len_linesInfo == 7 and r.lineIm.shape == img.shape and r.lineIm.dtype == np.uint8
+    r2 = lsdmod.runLSD(img.copy(), ctx=ctx)
+    assert r2.linesInfo.tobytes() == r.linesInfo.tobytes()
+    ref = oracle.lsd(img.copy())
+    assert_lines_close(r.linesInfo, ref["lines"])
+
+
+def test_batch_equals_single(maps, lsdmod, ctx):
+    src = maps["aisle2"][:600, :1600]
+    batch = np.stack([src, src[::-1].copy(), src[:, ::-1].copy(), np.roll(src, 37, 1)]).copy()
+    lines, offs, ims = ctx.run_batch(batch.copy())
+    assert offs[0] == 0 and len(offs) == 5
+    for i in range(4):
+        l1, im1 = ctx.run(batch[i].copy())
+        assert lines[offs[i]:offs[i + 1]].tobytes() == l1.tobytes()
+        assert np.array_equal(ims[i], im1)
+
+
+def test_deterministic(maps, lsdmod, ctx):
+    a = ctx.run(maps["aisle3"].copy())
+    b = ctx.run(maps["aisle3"].copy())
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+
+
+def test_non_packed_stride(maps, lsdmod, ctx, oracle):
+    img = maps["map1"]
+    rows, cols = img.shape
+    big = np.zeros((rows, cols + 24), np.uint8)
+    big[:, :cols] = img
+    view = big[:, :cols]
+    p = lsdmod.make_params()
+    import ctypes as C
+    line_im = np.zeros((rows, cols + 8), np.uint8)
+    lines_p, n = C.c_void_p(), C.c_int()
+    st = ctx.L.lsd_run(ctx.h, view.ctypes.data, cols, rows, big.strides[0], C.byref(p), line_im.ctypes.data,
+                       line_im.strides[0], C.byref(lines_p), C.byref(n))
+    assert st == 0 and n.value == 7
+    ctx.L.lsd_free(lines_p)
+    ref_map = img.copy()
+    ref = oracle.lsd(ref_map)
+    assert np.array_equal(big[:, :cols], ref_map) and not big[:, cols:].any()
+    assert np.array_equal(line_im[:, :cols], ref["lineIm"]) and not line_im[:, cols:].any()
+
+
+@pytest.mark.parametrize("kw", [dict(sig=0.8), dict(angThre=20.0), dict(denThre=0.6), dict(pseBin=512),
+                                dict(sig=0.45, angThre=30.0, denThre=0.8, pseBin=256)])
+def test_other_parameters(kw, maps, lsdmod, ctx, oracle):
+    full = dict(sca=0.3, sig=0.6, angThre=22.5, denThre=0.7, pseBin=1024)
+    full.update(kw)
+    full_check(lsdmod, ctx, oracle, maps["mapValue"], lsdmod.make_params(**full), kw=full)
+
+
+def synth(seed, rows, cols):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((rows, cols), np.uint8)
+    m[rng.random((rows, cols)) < 0.35] = 255                                  # unknown cells
+    for _ in range(12):                                                       # walls: axis-aligned and slanted
+        x0, y0 = rng.integers(5, cols - 5), rng.integers(5, rows - 5)
+        L = int(rng.integers(30, 200)); a = rng.choice([0, np.pi / 2, rng.uniform(0, np.pi)])
+        t = np.arange(L)
+        xs = np.clip((x0 + t * np.cos(a)).astype(int), 0, cols - 1); ys = np.clip((y0 + t * np.sin(a)).astype(int), 0, rows - 1)
+        m[ys, xs] = 1
+    return m
+
+
+@pytest.mark.parametrize("seed,rows,cols", [(1, 240, 320), (2, 333, 517), (3, 101, 999), (4, 700, 64)])
+def test_synthetic_ragged_sizes(seed, rows, cols, lsdmod, ctx, oracle):
+    """Odd sizes (tiles that straddle the border, w or h not multiples of anything), exact ties from
+    axis-aligned walls (NaN/inf rectangle slopes)."""
+    full_check(lsdmod, ctx, oracle, synth(seed, rows, cols))
+
+
+def test_blank_and_minimum_images(lsdmod, ctx, oracle):
+    lines, im = ctx.run(np.zeros((64, 80), np.uint8))
+    assert len(lines) == 0 and not im.any()
+    lines, im = ctx.run(np.full((40, 40), 255, np.uint8))
+    assert len(lines) == 0
+    with pytest.raises(lsdmod.LsdError) as e:                                 # scaled size < 2: nothing to do
+        ctx.run(np.zeros((5, 5), np.uint8))
+    assert e.value.status == lsdmod.LSD_ERR_INVALID
+    with pytest.raises(lsdmod.LsdError) as e:
+        ctx.run(np.zeros((64, 64), np.uint8), lsdmod.make_params(pseBin=4096))
+    assert e.value.status == lsdmod.LSD_ERR_UNSUPPORTED
+
+
+def test_border_pixels_keep_raw_values(maps, lsdmod, ctx, oracle):
+    img = maps["map1"].copy()
+    img[0, 10:200] = 1; img[5:300, 0] = 255; img[0, 0] = 1
+    full_check(lsdmod, ctx, oracle, img)
+
+
+def test_line_capacity_is_reported(maps, lsdmod, ctx):
+    import torch
+    img = torch.from_numpy(maps["aisle1"].copy()).cuda()
+    rows, cols = img.shape
+    lines = torch.zeros((1, 8, 10), dtype=torch.int64, device="cuda")
+    counts = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.enqueue_device(img.data_ptr(), 1, cols, rows, lines.data_ptr(), 8, counts.data_ptr(),
+                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(counts[0]) == 75                                              # true count, only 8 stored
+
+
+def test_device_resident_batch_with_torch(maps, lsdmod, ctx, oracle):
+    """The device entry point on torch-owned HBM buffers and torch's stream (the bench's path)."""
+    import torch
+    src = maps["aisle3"]
+    batch = np.stack([src, np.roll(src, 11, 0), src[::-1].copy()]).copy()
+    n, rows, cols = batch.shape
+    d_maps = torch.from_numpy(batch).cuda()
+    max_lines = 512
+    d_lines = torch.zeros((n, max_lines, 10), dtype=torch.int64, device="cuda")
+    d_counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_ims = torch.zeros((n, rows, cols), dtype=torch.uint8, device="cuda")
+    ctx.enqueue_device(d_maps.data_ptr(), n, cols, rows, d_lines.data_ptr(), max_lines, d_counts.data_ptr(),
+                       d_line_ims=d_ims.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_maps.cpu().numpy(), batch)                        # read-only without the write-back flag
+    counts = d_counts.cpu().numpy()
+    raw = d_lines.cpu().numpy()
+    for i in range(n):
+        ref = oracle.lsd(batch[i].copy())
+        assert counts[i] == len(ref["lines"])
+        got = raw[i, :counts[i]].copy().view(np.uint8).reshape(-1, 80).view(lsdmod.LINE_DTYPE).reshape(-1)
+        assert_lines_close(got, ref["lines"])
+        assert np.array_equal(d_ims[i].cpu().numpy(), ref["lineIm"])
+
+
+def test_full_size_batch_properties(maps, lsdmod, ctx, oracle):
+    """BASELINE config 4 shape (2048x2048 tiles), a slice of the batch: image 0 is the unshifted aisle1
+    tile whose reference answer is recorded; replicas must agree bit for bit; every output is a valid raster."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    batch = bench.make_batch(maps, 6, 2048, first=0)
+    batch = np.concatenate([batch, batch[:2]])                                # replicas of images 0 and 1
+    lines, offs, ims = ctx.run_batch(batch.copy())
+    cnt = np.diff(offs)
+    assert cnt[0] == 238 and int((ims[0] == 255).sum()) == 20296              # SURVEY 8c tile2048
+    assert cnt[6] == cnt[0] and cnt[7] == cnt[1]
+    assert lines[offs[6]:offs[7]].tobytes() == lines[offs[0]:offs[1]].tobytes()
+    assert lines[offs[7]:offs[8]].tobytes() == lines[offs[1]:offs[2]].tobytes()
+    assert np.array_equal(ims[6], ims[0]) and np.array_equal(ims[7], ims[1])
+    assert set(np.unique(ims)) <= {0, 255}
+    for i in (1, 3):                                                          # spot-check two against the oracle
+        ref = oracle.lsd(batch[i].copy())
+        assert_lines_close(lines[offs[i]:offs[i + 1]], ref["lines"])
+        assert np.array_equal(ims[i], ref["lineIm"])
+    for i in range(8):                                                        # every line lies inside the canvas, len consistent
+        L = lines[offs[i]:offs[i + 1]]
+        assert np.all(L["len"] > 0) and np.all(np.abs(np.hypot(L["x2"] - L["x1"], L["y2"] - L["y1"]) - L["len"]) < 1e-9)
+
+
+def test_cpp_adapter_runs(maps, tmp_path):
+    """The C++ host side (include/myLSD.h) end to end: same line count as the recorded reference answer."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "linesegmentdetector-slam_amd")
+    img = maps["map1"]
+    raw = tmp_path / "map1.raw"
+    img.tofile(raw)
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "myLSD.h"\n#include <cstdio>\n'
+        'int main(int argc, char** argv) {\n'
+        '  mylsd::Mat m = mylsd::make_u8(480, 608);\n'
+        '  FILE* f = fopen(argv[1], "rb"); size_t n = fread(m.ptr<unsigned char>(0), 1, 480*608, f); fclose(f);\n'
+        '  mylsd::structLSD r = mylsd::myLineSegmentDetector(m, 608, 480, lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin);\n'
+        '  long lit = 0; for (int y = 0; y < 480; y++) for (int x = 0; x < 608; x++) lit += r.lineIm.ptr<unsigned char>(y)[x] == 255;\n'
+        '  std::printf("%zu %d %ld %.17g %d\\n", n, r.len_linesInfo, lit, r.linesInfo[0].x1, (int)m.ptr<unsigned char>(3)[3]);\n'
+        '  free(r.linesInfo); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", pkg, "-llsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    p = subprocess.run([str(exe), str(raw)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    n, nl, lit, x1, _ = p.stdout.split()
+    assert int(n) == 480 * 608 and int(nl) == 7 and int(lit) == 545
+    assert abs(float(x1) - 351.00301936775691) < ENDPOINT_TOL
