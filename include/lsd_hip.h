@@ -128,6 +128,10 @@ enum { LSD_DBG_GAUSS = 1, LSD_DBG_MAG, LSD_DBG_DEG, LSD_DBG_STATE, LSD_DBG_ORDER
        LSD_DBG_NB, LSD_DBG_MAXGRAD, LSD_DBG_RECS, LSD_DBG_SEEDS, LSD_DBG_NSEED, LSD_DBG_STATS };
 int lsd_debug_fetch(lsd_ctx *ctx, int image, int what, void *out, size_t bytes);
 
+/* Test hook: evaluates the DEVICE build of the path's transcendental functions on host arrays of n
+ * doubles: fn 0 = sin/cos(a) -> out0,out1; fn 1 = atan2(a, b) -> out0; fn 2 = atan(a) -> out0. */
+int lsd_debug_eval_math(lsd_ctx *ctx, int fn, const double *a, const double *b, double *out0, double *out1, size_t n);
+
 /* Per-kernel device time (ms) of the last lsd_run/lsd_run_batch, measured with HIP events on the
  * context's stream: [0] gauss, [1] gradient, [2] sort, [3] region, [4] lines, [5] total. */
 int lsd_last_timings(lsd_ctx *ctx, float ms_out[6]);

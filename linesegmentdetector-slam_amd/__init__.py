@@ -85,6 +85,7 @@ def load_library(path=None):
     L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
     L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
         _lib = L
     return L
@@ -93,7 +94,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
                     "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
-                    "lsd_debug_fetch", "lsd_last_timings"]
+                    "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math"]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -228,6 +229,15 @@ class Context:
             ns = self.fetch(image, DBG_NSEED, shape_wh)
             return get(what, SEED_DTYPE, ns)
         raise ValueError(what)
+
+    def eval_math(self, fn, a, b=None):
+        """Device sin/cos (fn 0), atan2(a, b) (fn 1) or atan (fn 2) of float64 arrays (test hook)."""
+        a = np.ascontiguousarray(a, np.float64)
+        b = None if b is None else np.ascontiguousarray(b, np.float64)
+        o0, o1 = np.zeros_like(a), np.zeros_like(a)
+        self._chk(self.L.lsd_debug_eval_math(self.h, fn, a.ctypes.data, None if b is None else b.ctypes.data,
+                                             o0.ctypes.data, o1.ctypes.data, a.size))
+        return o0, o1
 
     def fetch_recs(self, image, count):
         a = np.zeros(max(count * 12, 1), np.float64)

@@ -1,0 +1,25 @@
+// devmath.h -- the transcendental functions used on the LSD path, glibc-compatible rounding.
+// sin/cos/atan/atan2 go through crmath.h (correctly rounded, see there for why); the rare inputs it
+// declines (non-finite, |x| > 64, subnormal range) fall back to the device math library.
+#pragma once
+#include "crmath.h"
+
+namespace lsdhip {
+
+__device__ inline void sincos_g(double x, double& s, double& c) {
+    if (!crm::sincos_cr(x, s, c)) { s = sin(x); c = cos(x); }
+}
+__device__ inline double sin_g(double x) { double s, c; sincos_g(x, s, c); return s; }
+__device__ inline double cos_g(double x) { double s, c; sincos_g(x, s, c); return c; }
+__device__ inline double atan2_g(double y, double x) {
+    double r;
+    if (!crm::atan2_cr(y, x, r)) r = atan2(y, x);
+    return r;
+}
+__device__ inline double atan_g(double v) {
+    double r;
+    if (!crm::atan_cr(v, r)) r = atan(v);
+    return r;
+}
+
+}  // namespace lsdhip

@@ -6,6 +6,7 @@
 // writes the usedMap value into the low bits of a 32-bit state word (the upper bits later hold
 // the curMap stamp of the region stage), i.e. 8 + 20 B per pixel actually move.
 #include "lsd_internal.h"
+#include "devmath.h"
 
 namespace lsdhip {
 
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(GX* GY) void k_gradient(const double* __restrict__ 
             const double gradY = (C + D - A - B) / 2.0;        // :162
             m = sqrt(gradX * gradX + gradY * gradY);           // :163 (pow(.,2) == x*x, Q12)
             if (m < gradThre) u = 1;                           // :165-166
-            d = atan2(gradX, -gradY);                          // :169
+            d = atan2_g(gradX, -gradY);                        // :169
             if (fabs(d - kPi) < 0.000001) d = 0;               // :170-171
         }
         const size_t p = base + (size_t)y * w + x;

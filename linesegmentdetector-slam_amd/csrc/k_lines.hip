@@ -4,6 +4,7 @@
 // one wavefront per line (strided); lanes walk the samples of the longer axis.  lineIm has been
 // cleared by a memset node on the same stream; marking 255 is idempotent so store order is free.
 #include "lsd_internal.h"
+#include "devmath.h"
 
 namespace lsdhip {
 
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void k_lines(const double* __restrict__ recs_s
     for (int i = wave; i < n; i += 4) {
         const double x1 = rs[i * 4 + 0], y1 = rs[i * 4 + 1], x2 = rs[i * 4 + 2], y2 = rs[i * 4 + 3];
         const double k = (y2 - y1) / (x2 - x1);                                    // :289
-        double ang = atan(k) * 180.0 / kPi;                                        // atand, baseFunc.cpp:14-16
+        double ang = atan_g(k) * 180.0 / kPi;                                        // atand, baseFunc.cpp:14-16
         int orient = 1;
         if (ang < 0) { ang += 180; orient = -1; }                                  // :292-295
         int xLow, xHigh, yLow, yHigh;
@@ -53,8 +54,7 @@ __global__ __launch_bounds__(256) void k_lines(const double* __restrict__ recs_s
             lsd_line L;
             L.k = k;
             L.b = (y1 + y2) / 2.0 - k * (x1 + x2) / 2.0;                           // :359
-            L.dx = cos(ang / 180.0 * kPi);                                         // cosd
-            L.dy = sin(ang / 180.0 * kPi);                                         // sind
+            sincos_g(ang / 180.0 * kPi, L.dy, L.dx);                               // sind / cosd
             L.x1 = x1; L.y1 = y1; L.x2 = x2; L.y2 = y2;
             const double ey = y2 - y1, ex = x2 - x1;
             L.len = sqrt(ey * ey + ex * ex);                                       // :366

@@ -18,6 +18,7 @@
 //   * usedMap marking: only the region's pixels are visited (the reference scans the whole image).
 // curMap is a stamp in the upper 30 bits of the per-pixel state word (no per-call clearing).
 #include "lsd_internal.h"
+#include "devmath.h"
 
 namespace lsdhip {
 
@@ -81,7 +82,8 @@ __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double
         const size_t q = (size_t)sy * w + sx;
         c.state[q] = (id << 2) | (c.state[q] & 3u);          // :520
     }
-    double sinS = sin(regDeg), cosS = cos(regDeg);           // :515-516
+    double sinS, cosS;
+    sincos_g(regDeg, sinS, cosS);                            // :515-516
     int n = 1;
     wg_fence();
     const int e = lane >> 3, k = lane & 7;
@@ -109,12 +111,12 @@ __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double
                 if (!pass) break;
                 const int l = __builtin_ctzll(pass);          // first passing candidate in reference order
                 if (!have_sc) {
-                    if ((rem >> lane) & 1ull) { sd = sin(d); cd = cos(d); }
+                    if ((rem >> lane) & 1ull) sincos_g(d, sd, cd);
                     have_sc = true;
                 }
                 cosS += rl(cd, l);                            // :545
                 sinS += rl(sd, l);                            // :546
-                regDeg = atan2(sinS, cosS);                   // :547
+                regDeg = atan2_g(sinS, cosS);                 // :547
                 const int ql = __builtin_amdgcn_readlane(q, l);
                 if (lane == l) {
                     c.state[q] = (id << 2) | (word & 3u);     // :549
@@ -186,15 +188,16 @@ __device__ __noinline__ void rect_convert(RCtx& c, int num, double regdeg, doubl
     const double dI = Ixx - Iyy;
     const double lamb = (Ixx + Iyy - sqrt(dI * dI + 4 * Ixy * Ixy)) / 2.0;          // :647
     double inertiaDeg;
-    if (fabs(Ixx) > fabs(Iyy)) inertiaDeg = atan2(lamb - Ixx, Ixy);               // :649-652
-    else inertiaDeg = atan2(Ixy, lamb - Iyy);
+    if (fabs(Ixx) > fabs(Iyy)) inertiaDeg = atan2_g(lamb - Ixx, Ixy);             // :649-652
+    else inertiaDeg = atan2_g(Ixy, lamb - Iyy);
     double regDif = inertiaDeg - regdeg;                                          // :655-665
     while (regDif <= -kPi) regDif += 2 * kPi;
     while (regDif > kPi) regDif -= 2 * kPi;
     if (regDif < 0) regDif = -regDif;
     if (regDif > tol) inertiaDeg += kPi;
 
-    const double dx = cos(inertiaDeg), dy = sin(inertiaDeg);                       // :699-700
+    double dx, dy;
+    sincos_g(inertiaDeg, dy, dx);                                                  // :699-700
     double lenMin = 0, lenMax = 0, widMin = 0, widMax = 0;                         // Q9: start at 0 (:701)
     for (int base = 0; base < num; base += 64) {
         const int kx = base + lane;

@@ -459,4 +459,19 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
     return LSD_OK;
 }
 
+int lsd_debug_eval_math(lsd_ctx* c, int fn, const double* a, const double* b, double* out0, double* out1, size_t n) {
+    if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 2 || (fn == 1 && !b)) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
+    HIPCHK(c, hipMalloc(&da, n * 8)); HIPCHK(c, hipMalloc(&db, n * 8)); HIPCHK(c, hipMalloc(&d0, n * 8)); HIPCHK(c, hipMalloc(&d1, n * 8));
+    HIPCHK(c, hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    if (b) HIPCHK(c, hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+    launch_dbgmath(fn, da, db, d0, d1, n, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out0, d0, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out1, d1, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(d0); (void)hipFree(d1);
+    return LSD_OK;
+}
+
 }  // extern "C"

@@ -70,6 +70,7 @@ void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_region(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 
 // x86-64 cvttsd2si semantics of the reference's (int) casts: NaN, +-inf and
 // out-of-range values give INT_MIN.  v_cvt_i32_f64 would give 0 / saturate instead.

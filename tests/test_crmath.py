@@ -1,0 +1,111 @@
+"""crmath.h (correctly rounded sin/cos/atan/atan2 in double-double): the host build against mpmath
+(must be the correctly rounded result every time) and against glibc (may differ only where glibc
+itself is not correctly rounded); the device build (-m gpu) must be bit-identical to the host build."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def crm(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("crm") / "libcrm_host.so")
+    flags = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
+                   ["-o", so, os.path.join(ROOT, "tests", "crmath_host.cpp"), "-lm"], check=True)
+    return C.CDLL(so)
+
+
+def samples():
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, 6000), rng.uniform(-7, 7, 2000),
+                         np.array([np.pi / 2, np.pi, -np.pi, -np.pi / 2, 1.5 * np.pi, 2 * np.pi, np.pi / 4, 1e-300, 1e-10,
+                                   -1e-5, 0.0, -0.0, np.pi / 32, 5 * np.pi / 32, 1.0, 0.5, 6.0, 63.9]),
+                         np.arange(-64, 65) * (np.pi / 32)])
+    th = rng.uniform(-np.pi, np.pi, 3000)
+    n = rng.integers(1, 2000, 3000)
+    ys = np.concatenate([rng.normal(0, 10, 4000), np.sin(th) * n, rng.uniform(-1, 1, 2000) * 10.0 ** rng.uniform(-12, 3, 2000),
+                         np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 1.0, 1.0, -1.0, 1e-20, 1.0, 3.0, 1.0])])
+    xx = np.concatenate([rng.normal(0, 10, 4000), np.cos(th) * n, rng.uniform(-1, 1, 2000) * 10.0 ** rng.uniform(-12, 3, 2000),
+                         np.array([1.0, 1.0, -1.0, -1.0, 0.0, 0.0, -0.0, 1.0, -1.0, 1.0, 1e-20, -4.0, 64.0])])
+    return xs, ys, xx
+
+
+def test_host_build_is_correctly_rounded(crm):
+    import mpmath as mp
+    mp.mp.prec = 300
+    xs, ys, xx = samples()
+    n = len(xs)
+    s, c = np.zeros(n), np.zeros(n)
+    assert crm.crm_sincos_n(P(xs), P(s), P(c), n) == 0
+    es = np.array([float(mp.sin(mp.mpf(float(v)))) for v in xs])
+    ec = np.array([float(mp.cos(mp.mpf(float(v)))) for v in xs])
+    assert np.array_equal(s, es) and np.array_equal(c, ec)
+    n = len(ys)
+    o = np.zeros(n)
+    assert crm.crm_atan2_n(P(ys), P(xx), P(o), n) == 0
+    e = np.array([float(mp.atan2(mp.mpf(float(a)), mp.mpf(float(b)))) for a, b in zip(ys, xx)])
+    nz = ys != 0                                                  # mpmath has no signed zero
+    assert np.array_equal(o[nz], e[nz]) and np.array_equal(np.signbit(o[nz]), np.signbit(e[nz]))
+    o2 = np.zeros(n)
+    crm.libm_atan2_n(P(ys), P(xx), P(o2), n)                      # IEEE special cases: like glibc
+    assert np.array_equal(o[~nz], o2[~nz]) and np.array_equal(np.signbit(o[~nz]), np.signbit(o2[~nz]))
+    v = np.concatenate([ys[:3000] / np.where(xx[:3000] == 0, 1, xx[:3000]), [np.inf, -np.inf, 0.0, -0.0, 1e308, 1e-200]])
+    o = np.zeros(len(v))
+    assert crm.crm_atan_n(P(v), P(o), len(v)) == 0
+    e = np.array([float(mp.atan(mp.mpf(float(a)))) if np.isfinite(a) else np.sign(a) * float(mp.pi / 2) for a in v])
+    assert np.array_equal(o, e)
+
+
+def test_glibc_differs_only_by_its_own_misroundings(crm):
+    """glibc's sin/cos/atan2 are within ~0.52 ulp: they disagree with the correctly rounded value in a
+    fraction of a percent of the calls, always by exactly one ulp."""
+    xs, ys, xx = samples()
+    n = len(xs)
+    s, c, s2, c2 = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    crm.crm_sincos_n(P(xs), P(s), P(c), n)
+    crm.libm_sincos_n(P(xs), P(s2), P(c2), n)
+    for a, b in ((s, s2), (c, c2)):
+        d = np.abs(a.view(np.int64) - b.view(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    n = len(ys)
+    o, o2 = np.zeros(n), np.zeros(n)
+    crm.crm_atan2_n(P(ys), P(xx), P(o), n)
+    crm.libm_atan2_n(P(ys), P(xx), P(o2), n)
+    d = np.abs(o.view(np.int64) - o2.view(np.int64))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_device_build_matches_host_build(crm, lsdmod):
+    ctx = lsdmod.Context(0)
+    xs, ys, xx = samples()
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([xs, rng.uniform(-np.pi, np.pi, 200000)])
+    ys = np.concatenate([ys, rng.normal(0, 30, 200000)])
+    xx = np.concatenate([xx, rng.normal(0, 30, 200000)])
+    n = len(xs)
+    s, c = np.zeros(n), np.zeros(n)
+    crm.crm_sincos_n(P(xs), P(s), P(c), n)
+    ds, dc = ctx.eval_math(0, xs)
+    assert np.array_equal(ds, s) and np.array_equal(dc, c)
+    n = len(ys)
+    o = np.zeros(n)
+    crm.crm_atan2_n(P(ys), P(xx), P(o), n)
+    do, _ = ctx.eval_math(1, ys, xx)
+    assert np.array_equal(do, o) and np.array_equal(np.signbit(do), np.signbit(o))
+    v = ys / np.where(xx == 0, 1, xx)
+    o = np.zeros(len(v))
+    crm.crm_atan_n(P(v), P(o), len(v))
+    do, _ = ctx.eval_math(2, v)
+    assert np.array_equal(do, o)
+    ctx.close()

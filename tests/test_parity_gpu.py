@@ -219,8 +219,8 @@ def test_synthetic_ragged_sizes(seed, rows, cols, lsdmod, ctx, oracle):
 def test_blank_and_minimum_images(lsdmod, ctx, oracle):
     lines, im = ctx.run(np.zeros((64, 80), np.uint8))
     assert len(lines) == 0 and not im.any()
-    lines, im = ctx.run(np.full((40, 40), 255, np.uint8))
-    assert len(lines) == 0
+    # all-unknown map: row 0 / col 0 keep 255 while the interior is remapped to 0 (Q2) -> a border edge
+    full_check(lsdmod, ctx, oracle, np.full((40, 40), 255, np.uint8))
     with pytest.raises(lsdmod.LsdError) as e:                                 # scaled size < 2: nothing to do
         ctx.run(np.zeros((5, 5), np.uint8))
     assert e.value.status == lsdmod.LSD_ERR_INVALID
