@@ -60,6 +60,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    try:
+        # torch bundles its own libamdhip64.so.7; when torch is used in the same process (device buffers,
+        # streams, RCCL) it must be the HIP runtime that gets loaded first, or the two runtimes clash.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise ImportError("liblsdhip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "-- there is no CPU fallback" % p)
@@ -221,10 +227,11 @@ class Context:
         if what == DBG_ORDER_VAL:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
-            v = get(what, np.int64, 16)
+            v = get(what, np.int64, 24)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                              "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
-                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds"), [int(x) for x in v]))
+                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
+                             "tile_fetches"), [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)
             return get(what, SEED_DTYPE, ns)

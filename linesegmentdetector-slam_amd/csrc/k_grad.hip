@@ -4,7 +4,8 @@
 // scaled pixel, 64x4 tiles; the 2x2 stencil is read through LDS (65x5 window, coalesced rows).
 // Algorithmic traffic: 8 B read + 8+8+1 B written per scaled pixel; this kernel
 // writes the usedMap value into the low bits of a 32-bit state word (the upper bits later hold
-// the curMap stamp of the region stage), i.e. 8 + 20 B per pixel actually move.
+// the curMap stamp of the region stage), i.e. 8 + 20 B per pixel actually move, plus 16 B for the
+// ~7 % of pixels that stay growable (sin/cos of their angle, consumed by the region stage).
 #include "lsd_internal.h"
 #include "devmath.h"
 
@@ -13,7 +14,8 @@ namespace lsdhip {
 constexpr int GX = 64, GY = 4;
 
 __global__ __launch_bounds__(GX* GY) void k_gradient(const double* __restrict__ gauss, double* __restrict__ mag,
-                                                     double* __restrict__ deg, uint32_t* __restrict__ state,
+                                                     double* __restrict__ deg, double* __restrict__ sn,
+                                                     double* __restrict__ cs, uint32_t* __restrict__ state,
                                                      unsigned long long* __restrict__ maxbits, int w, int h,
                                                      double gradThre) {
     __shared__ double t[GY + 1][GX + 1];
@@ -51,6 +53,12 @@ __global__ __launch_bounds__(GX* GY) void k_gradient(const double* __restrict__ 
         mag[p] = m;
         deg[p] = d;
         state[p] = u;
+        if (u == 0) {                      // growable pixels: sin/cos of the level-line angle for RegionGrower (:545-546)
+            double sv, cv;
+            sincos_g(d, sv, cv);
+            sn[p] = sv;
+            cs[p] = cv;
+        }
     }
     // per-image max (myLSD.cpp:167-168): non-negative doubles order like their bit patterns
     unsigned long long bits = (unsigned long long)__double_as_longlong(m);
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(GX* GY) void k_gradient(const double* __restrict__ 
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     dim3 grid((g.w + GX - 1) / GX, (g.h + GY - 1) / GY, n);
-    hipLaunchKernelGGL(k_gradient, grid, dim3(GX, GY), 0, s, b.gauss, b.mag, b.deg, b.state, b.maxbits, g.w, g.h,
+    hipLaunchKernelGGL(k_gradient, grid, dim3(GX, GY), 0, s, b.gauss, b.mag, b.deg, b.sn, b.cs, b.state, b.maxbits, g.w, g.h,
                        g.gradThre);
 }
 

@@ -22,7 +22,8 @@
 
 namespace lsdhip {
 
-constexpr int LCAP = 1024;  // region-list entries kept in LDS; the rest spills to HBM
+constexpr int LCAP = 4096;   // region-list entries kept in LDS; the rest spills to HBM
+constexpr int NSLOT = 16;    // tile-cache slots
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
@@ -36,7 +37,18 @@ struct RCtx {
     uint32_t* state;
     uint32_t* spill;
     uint32_t* gcopy;
-    uint32_t* lst;       // LDS
+    const double* sn;
+    const double* cs;
+    uint32_t* lst;       // LDS [LCAP]
+    uint16_t* wl0;       // LDS [LCAP] sweep worklists
+    uint16_t* wl1;
+    uint32_t* t_st;      // LDS [NSLOT][64] tile cache: state words
+    double* t_deg;       // LDS [NSLOT][64]
+    double* t_sn;        // LDS [NSLOT][64]
+    double* t_cs;        // LDS [NSLOT][64]
+    int* t_tag;          // LDS [NSLOT]
+    int tilesX;
+    bool dirty;          // stamps stored to HBM since the last fence
     int* s_incl;         // LDS [64]
     int* s_lo;           // LDS [64]
     int* s_x;            // LDS [64]
@@ -48,6 +60,7 @@ struct RCtx {
     const double* ptab;
     long long st_grow, st_grown, st_nfa, st_rrr, st_rrrpass, st_sent, st_oob, st_spill;
     long long t_grow, t_rect, t_nfa, t_mark, st_maxreg, st_nfapx;   // cycle counters (s_memtime) + extremes
+    long long st_exact, st_tilefetch;
 };
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -70,65 +83,223 @@ __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp
 }
 
 // ---------------------------------------------------------------------------------------------
-// RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order), returns num and angle.
+// LDS tile cache: 8x8-pixel tiles of (state, deg, sin deg, cos deg), direct-mapped over a
+// 64x16-pixel window (slot = tx&7 | (ty&1)<<3).  RegionGrower reads its 3x3 neighbourhoods from
+// here, so a batch costs LDS latency instead of two dependent HBM round trips plus a store fence.
+// Accepted pixels are stamped in the LDS copy AND in HBM (write-through, never waited for); the
+// cache is dropped whenever usedMap marks change (mark_region).
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double tol, int& out_num,
-                                  double& out_deg) {
+__device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx & 7) | ((ty & 1) << 3); }
+
+// Makes the tiles of every lane with need==true resident.  Returns false when two needed tiles map
+// to the same slot (the caller retries with a smaller batch; a single 3x3 neighbourhood never conflicts).
+__device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py) {
+    const int lane = c.lane, w = c.w, h = c.h;
+    const int tx = px >> 3, ty = py >> 3;
+    const int tile = need ? ty * c.tilesX + tx : -1;
+    const int slot = tile_slot(tx, ty);
+    unsigned long long todo = __ballot(need && c.t_tag[slot] != tile);
+    if (!todo) return true;
+    // conflict check over all needed tiles (resident ones included)
+    {
+        unsigned long long chk = __ballot(need);
+        while (chk) {
+            const int l = __builtin_ctzll(chk);
+            const int T = __builtin_amdgcn_readlane(tile, l), S = __builtin_amdgcn_readlane(slot, l);
+            if (__ballot(need && slot == S && tile != T)) return false;
+            chk &= ~__ballot(tile == T);
+        }
+    }
+    if (c.dirty) { wg_fence(); c.dirty = false; }     // earlier stamps must have landed before a tile is (re)read
+    c.st_tilefetch++;
+    while (todo) {
+        // up to 4 missing tiles per round, all loads in flight together
+        int T[4], S[4];
+        int nt = 0;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            T[j] = -1; S[j] = 0;
+            if (todo) {
+                const int l = __builtin_ctzll(todo);
+                T[j] = __builtin_amdgcn_readlane(tile, l);
+                S[j] = __builtin_amdgcn_readlane(slot, l);
+                todo &= ~__ballot(tile == T[j]);
+                nt++;
+            }
+        }
+        double vd[4], vs[4], vc[4];
+        uint32_t vw[4];
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            vd[j] = 0; vs[j] = 0; vc[j] = 1; vw[j] = 1u;          // outside the image: banned
+            if (j < nt) {
+                const int ttx = T[j] % c.tilesX, tty = T[j] / c.tilesX;
+                const int x = ttx * 8 + (lane & 7), y = tty * 8 + (lane >> 3);
+                if (x < w && y < h) {
+                    const size_t q = (size_t)y * w + x;
+                    vw[j] = c.state[q];
+                    vd[j] = c.deg[q];
+                    if ((vw[j] & 3u) != 1u) { vs[j] = c.sn[q]; vc[j] = c.cs[q]; }
+                }
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < nt) {
+                c.t_st[S[j] * 64 + lane] = vw[j];
+                c.t_deg[S[j] * 64 + lane] = vd[j];
+                c.t_sn[S[j] * 64 + lane] = vs[j];
+                c.t_cs[S[j] * 64 + lane] = vc[j];
+                if (lane == 0) c.t_tag[S[j]] = T[j];
+            }
+        }
+    }
+    wg_fence();
+    return true;
+}
+
+__device__ __forceinline__ void invalidate_tiles(RCtx& c) {
+    if (c.lane < NSLOT) c.t_tag[c.lane] = -1;
+    wg_fence();
+}
+
+// ---------------------------------------------------------------------------------------------
+// RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order); returns the size and
+// the angle sums (the region angle atan2(sinS, cosS) is evaluated by the caller only when needed).
+//
+// Exactness: the reference tests every candidate against regDeg = atan2(sinDeg, cosDeg) recomputed
+// after each accepted pixel (:545-547).  Here the sums are accumulated exactly in the reference
+// order, the angle used for the tests is a cheap fp32 estimate with a rigorous error bound, and the
+// correctly rounded angle is computed only for candidates whose test is within that bound of the
+// threshold -- every decision is the one the exact angle would give.
+// Sweeps after the first revisit only the entries that still had a non-member, non-banned
+// neighbour (membership and bans only grow during one call, so the others cannot accept anything).
+// ---------------------------------------------------------------------------------------------
+constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
+
+__device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, double tol, int& out_num,
+                                  double& out_sin, double& out_cos) {
     const int lane = c.lane, w = c.w, h = c.h;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     const uint32_t id = ++c.cur_id;                          // fresh curMap (:519)
-    if (lane == 0) {
-        lset(c, 0, pack_xy(sx, sy));
-        const size_t q = (size_t)sy * w + sx;
-        c.state[q] = (id << 2) | (c.state[q] & 3u);          // :520
-    }
+    ensure_tiles(c, lane == 0, sx, sy);
     double sinS, cosS;
-    sincos_g(regDeg, sinS, cosS);                            // :515-516
+    {
+        const int slot = tile_slot(sx >> 3, sy >> 3), ti = ((sy & 7) << 3) | (sx & 7);
+        sinS = c.t_sn[slot * 64 + ti];                       // sin/cos(regDeg0): regDeg0 is degMap[seed] at both call sites (:225, :857)
+        cosS = c.t_cs[slot * 64 + ti];
+        if (lane == 0) {
+            lset(c, 0, pack_xy(sx, sy));
+            const uint32_t wd = (id << 2) | (c.t_st[slot * 64 + ti] & 3u);
+            c.t_st[slot * 64 + ti] = wd;                     // :520
+            c.state[(size_t)sy * w + sx] = wd;
+        }
+        c.dirty = true;
+    }
+    double R = regDeg0;                                      // angle used by the tests
+    double eps = 0.0;                                        // 0: R is the exact reference value
     int n = 1;
     wg_fence();
     const int e = lane >> 3, k = lane & 7;
     const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
     const int ox = kk % 3 - 1, oy = kk / 3 - 1;
-    int ex;
+    uint16_t* wl_cur = c.wl0;
+    uint16_t* wl_nxt = c.wl1;
+    int wl_cnt = 0;                                          // entries of wl_cur (sweep >= 2)
+    bool filter = true;                                      // false once the list outgrew the worklists
+    int sweep = 1, ex;
     do {                                                     // :525 sweeps to fixpoint (Q7)
         ex = n;
-        for (int i = 0; i < n;) {                            // n is live (:529)
-            const int cnt = min(8, n - i);
-            const bool valid = e < cnt;
-            const uint32_t pk = valid ? lget(c, i + e) : 0u;
-            const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
-            const bool inb = valid && nx >= 0 && ny >= 0 && nx < w && ny < h;      // :536
+        int nxt_cnt = 0;
+        const int n_start = (sweep == 1) ? 0 : n;            // entries below n_start come from the worklist
+        int wi = 0;                                          // worklist cursor
+        int i = (sweep == 1 || !filter) ? 0 : n_start;       // contiguous cursor
+        bool in_wl = (sweep > 1) && filter;
+        while (true) {
+            // ---- pick up to 8 entries ----
+            int cnt, eidx;
+            if (in_wl) {
+                if (wi >= wl_cnt) { in_wl = false; continue; }
+                cnt = min(8, wl_cnt - wi);
+                eidx = e < cnt ? (int)wl_cur[wi + e] : 0;
+            } else {
+                if (i >= n) break;                           // n is live (:529)
+                cnt = min(8, n - i);
+                eidx = i + e;
+            }
+            bool valid = e < cnt;
+            uint32_t pk = valid ? lget(c, eidx) : 0u;
+            int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+            bool inb = valid && nx >= 0 && ny >= 0 && nx < w && ny < h;            // :536
+            if (!ensure_tiles(c, inb, nx, ny)) {             // slot conflict: one entry at a time
+                cnt = 1;
+                valid = e < cnt;
+                inb = inb && valid;
+                ensure_tiles(c, inb, nx, ny);
+            }
+            const int slot = tile_slot(nx >> 3, ny >> 3), ti = ((ny & 7) << 3) | (nx & 7);
             const int q = ny * w + nx;
-            const uint32_t word = inb ? c.state[q] : 0u;
+            const uint32_t word = inb ? c.t_st[slot * 64 + ti] : 1u;
             const bool cand = inb && (word >> 2) != id && (word & 3u) != 1u;       // :537 (2 is growable, Q5)
-            const double d = cand ? c.deg[q] : 0.0;
+            const double d = cand ? c.t_deg[slot * 64 + ti] : 0.0;
             unsigned long long rem = __ballot(cand);
-            bool have_sc = false;
-            double sd = 0, cd = 0;
+            unsigned long long gone = 0;                     // candidates that became members in this batch
             while (rem) {
-                const double dif = angle_diff(regDeg, d);                         // :540-542
-                const unsigned long long pass = __ballot(cand && dif < tol) & rem; // :543
-                if (!pass) break;
-                const int l = __builtin_ctzll(pass);          // first passing candidate in reference order
-                if (!have_sc) {
-                    if ((rem >> lane) & 1ull) sincos_g(d, sd, cd);
-                    have_sc = true;
+                const double raw = fabs(R - d);
+                const double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;  // :540-542
+                bool pc, amb;
+                if (eps == 0.0) { pc = dif < tol; amb = false; }                   // :543
+                else {
+                    pc = dif < tol - eps;
+                    amb = !pc && !(dif > tol + eps);
+                    if (fabs(raw - kPi * 3 / 2.0) <= eps) { amb = true; pc = false; }
                 }
-                cosS += rl(cd, l);                            // :545
-                sinS += rl(sd, l);                            // :546
-                regDeg = atan2_g(sinS, cosS);                 // :547
+                const unsigned long long m_pc = __ballot(cand && pc) & rem;
+                const unsigned long long m_amb = __ballot(cand && amb) & rem;
+                const unsigned long long first = m_pc | m_amb;
+                if (!first) break;
+                const int l = __builtin_ctzll(first);        // first candidate in reference order that may pass
+                if ((m_amb >> l) & 1ull) {                   // too close to call with the estimate: exact angle
+                    R = atan2_g(sinS, cosS);                 // :547
+                    eps = 0.0;
+                    c.st_exact++;
+                    continue;
+                }
+                cosS += rl(c.t_cs[slot * 64 + ti], l);       // :545
+                sinS += rl(c.t_sn[slot * 64 + ti], l);       // :546
+                R = (double)atan2f((float)sinS, (float)cosS);
+                eps = kAngEps;
                 const int ql = __builtin_amdgcn_readlane(q, l);
                 if (lane == l) {
-                    c.state[q] = (id << 2) | (word & 3u);     // :549
-                    lset(c, n, pack_xy(nx, ny));              // :551-556
+                    const uint32_t wd = (id << 2) | (word & 3u);
+                    c.t_st[slot * 64 + ti] = wd;             // :549
+                    c.state[q] = wd;
+                    lset(c, n, pack_xy(nx, ny));             // :551-556
                 }
                 n++;
-                rem &= ~((2ull << l) - 1ull);                 // everything up to l has had its turn
-                rem &= ~__ballot(q == ql);                    // the same pixel seen from another frontier pixel
+                const unsigned long long same = __ballot(cand && q == ql);
+                gone |= same;
+                rem &= ~((2ull << l) - 1ull);                // everything up to l has had its turn
+                rem &= ~same;                                // the same pixel seen from another frontier pixel
+                c.dirty = true;
             }
-            wg_fence();
-            i += cnt;
+            // entries that still have a growable non-member neighbour go to the next sweep's worklist
+            if (filter) {
+                const unsigned long long left = __ballot(cand) & ~gone;
+                const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
+                const unsigned long long hm = __ballot(has && k == 0);
+                const int add = __builtin_popcountll(hm);
+                if (nxt_cnt + add > LCAP || n > 65535) filter = false;
+                else {
+                    if (has && k == 0) wl_nxt[nxt_cnt + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = (uint16_t)eidx;
+                    nxt_cnt += add;
+                }
+            }
+            if (in_wl) wi += cnt; else i += cnt;
         }
+        uint16_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
+        wl_cnt = nxt_cnt;
+        sweep++;
     } while (n != ex);
     c.gnum = n;
     c.has_copy = false;
@@ -138,13 +309,14 @@ __device__ __noinline__ void grow(RCtx& c, int sx, int sy, double regDeg, double
     if (n > c.st_maxreg) c.st_maxreg = n;
     c.t_grow += (long long)__builtin_amdgcn_s_memtime() - t0;
     out_num = n;
-    out_deg = regDeg;
+    out_sin = sinS;
+    out_cos = cosS;
 }
 
 // ---------------------------------------------------------------------------------------------
 // CenterGetter (:592-619) + OrientationGetter (:621-667) + RectangleConverter (:669-734)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
+__device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
                                           Rec& r) {
     const int lane = c.lane, w = c.w;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
@@ -233,7 +405,7 @@ __device__ __forceinline__ double rec_density(int num, const Rec& r) {          
 // ---------------------------------------------------------------------------------------------
 // RegionRadiusReducer, myLSD.cpp:736-802 (incl. the `i <= num` sentinel behaviour)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
+__device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
                                            double denThre) {
     const int lane = c.lane, w = c.w;
     c.st_rrr++;
@@ -243,6 +415,7 @@ __device__ __noinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num, do
     for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
     c.has_copy = true;
     wg_fence();
+    c.dirty = false;
     const double ax = sx - rec.x1, ay = sy - rec.y1, bx = sx - rec.x2, by = sy - rec.y2;
     const double rad1 = sqrt(ax * ax + ay * ay), rad2 = sqrt(bx * bx + by * by);    // :768-769
     double rad = rad1 > rad2 ? rad1 : rad2;
@@ -296,7 +469,7 @@ __device__ double log_gamma_dev(const RCtx& c, int x) {
 // ---------------------------------------------------------------------------------------------
 // RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
+__device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
     const int lane = c.lane, xLim = c.w, yLim = c.h;
     const double logNT = c.logNT;
     c.st_nfa++;
@@ -404,62 +577,47 @@ __device__ __forceinline__ double rect_nfa(RCtx& c, const Rec& rec) {
     return v;
 }
 
-// RectangleImprover, myLSD.cpp:1061-1158
-__device__ __noinline__ double improve(RCtx& c, Rec& rec_io) {
+// RectangleImprover, myLSD.cpp:1061-1158.  The reference's five hand-unrolled phases are walked by one
+// loop (step 0 = the initial evaluation, then 5 phases x 5 tries) so that the NFA code is inlined once.
+__device__ __forceinline__ double improve(RCtx& c, Rec& rec_io) {
     const double delt = 0.5, delt2 = delt / 2.0;
-    Rec best = rec_io;
-    double bestNFA = rect_nfa(c, best);
-    if (bestNFA > 0) return bestNFA;                                               // :1078
-    Rec r = best;
-    for (int i = 0; i < 5; i++) {                                                  // :1084-1092
-        r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
+    Rec best = rec_io, r = rec_io;
+    double bestNFA = 0;
+    for (int step = 0; step <= 25; step++) {
+        const int phase = step == 0 ? -1 : (step - 1) / 5;
+        if (step > 0 && (step - 1) % 5 == 0) {              // phase boundary (:1078,:1093,:1108,:1126,:1144)
+            if (bestNFA > 0) break;
+            r = best;
+        }
+        bool eval = true;
+        if (phase == 0 || phase == 4) {                     // :1084-1092 / :1148-1156  halve p
+            r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
+        } else if (phase == 1) {                            // :1097-1107  reduce width
+            if (r.wid - delt >= 0.5) r.wid -= delt; else eval = false;
+        } else if (phase == 2) {                            // :1112-1125  move one side
+            if (r.wid - delt >= 0.5) {
+                r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2;
+                r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2;
+                r.wid -= delt;
+            } else eval = false;
+        } else if (phase == 3) {                            // :1130-1143  move the other side
+            if (r.wid - delt >= 0.5) {
+                r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2;
+                r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2;
+                r.wid -= delt;
+            } else eval = false;
+        }
+        if (!eval) continue;
         const double v = rect_nfa(c, r);
-        if (v > bestNFA) { bestNFA = v; best = r; }
-    }
-    if (bestNFA > 0) { rec_io = best; return bestNFA; }
-    r = best;
-    for (int i = 0; i < 5; i++) {                                                  // :1097-1107
-        if (r.wid - delt >= 0.5) {
-            r.wid -= delt;
-            const double v = rect_nfa(c, r);
-            if (v > bestNFA) { bestNFA = v; best = r; }
-        }
-    }
-    if (bestNFA > 0) { rec_io = best; return bestNFA; }
-    r = best;
-    for (int i = 0; i < 5; i++) {                                                  // :1112-1125
-        if (r.wid - delt >= 0.5) {
-            r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2;
-            r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2;
-            r.wid -= delt;
-            const double v = rect_nfa(c, r);
-            if (v > bestNFA) { bestNFA = v; best = r; }
-        }
-    }
-    if (bestNFA > 0) { rec_io = best; return bestNFA; }
-    r = best;
-    for (int i = 0; i < 5; i++) {                                                  // :1130-1143
-        if (r.wid - delt >= 0.5) {
-            r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2;
-            r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2;
-            r.wid -= delt;
-            const double v = rect_nfa(c, r);
-            if (v > bestNFA) { bestNFA = v; best = r; }
-        }
-    }
-    if (bestNFA > 0) { rec_io = best; return bestNFA; }
-    r = best;
-    for (int i = 0; i < 5; i++) {                                                  // :1148-1156
-        r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
-        const double v = rect_nfa(c, r);
-        if (v > bestNFA) { bestNFA = v; best = r; }
+        if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
+        else if (v > bestNFA) { bestNFA = v; best = r; }
     }
     rec_io = best;
     return bestNFA;
 }
 
 // Refiner, myLSD.cpp:804-880
-__device__ __noinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& regdeg, Rec& rec, double denThre) {
+__device__ __forceinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& regdeg, Rec& rec, double denThre) {
     const int lane = c.lane, w = c.w;
     double den = rec_density(num, rec);
     if (den >= denThre) return true;                                               // :829
@@ -493,8 +651,10 @@ __device__ __noinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& r
     }
     const double meanDif = difSum / (ptNum * 1.0);
     const double tol2 = 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
-    grow(c, sx, sy, cenDeg, tol2, num, regdeg);                                    // :857
+    double gs, gc;
+    grow(c, sx, sy, cenDeg, tol2, num, gs, gc);                                    // :857
     if (num < 2) return false;                                                     // :861
+    regdeg = atan2_g(gs, gc);                                                      // reg.deg (:547, :581)
     rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec, rec);                    // :866
     den = rec_density(num, rec);
     if (den < denThre) return radius_reduce(c, sx, sy, num, regdeg, rec, denThre); // :869-877
@@ -507,6 +667,8 @@ __device__ __noinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& r
 __device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 restricted to the grown pixels
     const int w = c.w;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    wg_fence();                                   // the stamps written by grow() must have landed
+    c.dirty = false;
     for (int k2 = c.lane; k2 < c.gnum; k2 += 64) {
         const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
         const size_t q = (size_t)(pkx >> 16) * w + (pkx & 0xffffu);
@@ -514,11 +676,16 @@ __device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 re
         if ((word >> 2) == c.cur_id) c.state[q] = (word & ~3u) | val;   // curMap == 1 only
     }
     wg_fence();
+    invalidate_tiles(c);                          // cached usedMap bits are stale now
     c.t_mark += (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
 __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
     __shared__ uint32_t lst[LCAP];
+    __shared__ uint16_t wl0[LCAP], wl1[LCAP];
+    __shared__ double t_deg[NSLOT * 64], t_sn[NSLOT * 64], t_cs[NSLOT * 64];
+    __shared__ uint32_t t_st[NSLOT * 64];
+    __shared__ int t_tag[NSLOT];
     __shared__ int s_incl[64], s_lo[64], s_x[64];
     const size_t img = blockIdx.x;
     const int lane = threadIdx.x;
@@ -530,6 +697,11 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.state = b.state + img * npx;
     c.spill = b.spill + img * npx; c.gcopy = b.gcopy + img * npx;
     c.lst = lst; c.s_incl = s_incl; c.s_lo = s_lo; c.s_x = s_x;
+    c.sn = b.sn + img * npx; c.cs = b.cs + img * npx;
+    c.wl0 = wl0; c.wl1 = wl1; c.t_st = t_st; c.t_deg = t_deg; c.t_sn = t_sn; c.t_cs = t_cs; c.t_tag = t_tag;
+    c.tilesX = (w + 7) >> 3; c.dirty = false; c.st_exact = 0; c.st_tilefetch = 0;
+    if (lane < NSLOT) t_tag[lane] = -1;
+    wg_fence();
     c.cur_id = 0; c.gnum = 0; c.has_copy = false;
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
     c.st_grow = c.st_grown = c.st_nfa = c.st_rrr = c.st_rrrpass = c.st_sent = c.st_oob = c.st_spill = 0;
@@ -559,8 +731,9 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
                 if ((wd & 3u) != 0u) continue;
             }
             const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
-            int num; double regdeg;
-            grow(c, sx, sy, c.deg[pp], g.degThre, num, regdeg);                       // :225
+            int num; double regdeg, gs, gc;
+            const double seedDeg = c.deg[pp];
+            grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                         // :225
             SeedRec tr;
             tr.order_idx = base + l; tr.x = sx; tr.y = sy; tr.num = num; tr.outcome = 0; tr.final_num = num;
             tr.logNFA = 0;
@@ -568,6 +741,7 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
             Rec rec;
             if (num < g.regThre) done = true;                                        // :228 (not marked, Q5)
             if (!done) {
+                regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                         // reg.deg (:547, :581)
                 rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232
                 const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);      // :234
                 tr.final_num = num;
@@ -609,7 +783,8 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
         b.counts[img] = cntLines;
         if (b.nseed) b.nseed[img] = ntrace;
         if (b.stats) {
-            long long* st = b.stats + img * 16;
+            long long* st = b.stats + img * 24;
+            st[16] = c.st_exact; st[17] = c.st_tilefetch;
             st[0] = c.st_grow; st[1] = c.st_grown; st[2] = c.st_nfa; st[3] = c.st_rrr; st[4] = c.st_rrrpass;
             st[5] = c.st_sent; st[6] = c.st_oob; st[7] = c.st_spill;
             st[8] = (long long)__builtin_amdgcn_s_memtime() - t_begin; st[9] = c.t_grow; st[10] = c.t_rect;

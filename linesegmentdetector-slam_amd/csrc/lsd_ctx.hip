@@ -27,7 +27,8 @@ struct lsd_ctx {
     int cap_max_lines = 0;
     bool cap_trace = false;
     // workspace
-    double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
+    double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *sn = nullptr, *cs = nullptr, *recs = nullptr,
+           *recs_scaled = nullptr;
     uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr;
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
@@ -169,10 +170,11 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, hipDeviceSynchronize());
         const size_t tot = nn * pp;
         HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
+        HIPCHK(c, re_alloc(&c->sn, tot)); HIPCHK(c, re_alloc(&c->cs, tot));
         HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         HIPCHK(c, re_alloc(&c->spill, tot)); HIPCHK(c, re_alloc(&c->gcopy, tot));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * 16));
+        HIPCHK(c, re_alloc(&c->stats, nn * 24));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp;
@@ -244,7 +246,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -294,7 +296,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     Buffers b{};
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
-    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
@@ -451,7 +453,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * 16; need = 128; break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * 24; need = 192; break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

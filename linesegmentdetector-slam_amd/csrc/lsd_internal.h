@@ -35,6 +35,8 @@ struct Buffers {
     double* gauss;         // n x npx
     double* mag;           // n x npx
     double* deg;           // n x npx
+    double* sn;            // n x npx : sin(deg), written where usedMap == 0 after the gradient pass
+    double* cs;            // n x npx : cos(deg), same
     uint32_t* state;       // n x npx : (curMap stamp << 2) | usedMap value
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
