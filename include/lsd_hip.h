@@ -123,7 +123,8 @@ int lsd_set_trace(lsd_ctx *ctx, int on);
  *   NSEED          1 int32
  *   STATS          24 int64         grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, list_spills,
  *                                   cycles_total, cycles_grow, cycles_rect, cycles_nfa, cycles_mark, max_region, nfa_px, seeds,
- *                                   exact_angle_evals, tile_fetches, (6 reserved)
+ *                                   exact_angle_evals, tile_fetches, batches, cycles_tiles, spec_redos, spec_discards, cycles_wait, (1 reserved)
+ *                                   (counters are summed over the wavefronts that share an image)
  * Returns LSD_ERR_INVALID if `bytes` is smaller than the item. */
 enum { LSD_DBG_GAUSS = 1, LSD_DBG_MAG, LSD_DBG_DEG, LSD_DBG_STATE, LSD_DBG_ORDER, LSD_DBG_ORDER_VAL,
        LSD_DBG_NB, LSD_DBG_MAXGRAD, LSD_DBG_RECS, LSD_DBG_SEEDS, LSD_DBG_NSEED, LSD_DBG_STATS };

@@ -231,7 +231,8 @@ class Context:
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                              "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
                              "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches"), [int(x) for x in v]))
+                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait"),
+                            [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)
             return get(what, SEED_DTYPE, ns)

@@ -1,29 +1,38 @@
-// k_region.hip -- K4: the serial region stage, one wavefront (64 lanes) per image (gfx950).
+// k_region.hip -- K4: the region stage (seed loop) of LSD, one workgroup of NW wavefronts per image (gfx950).
 //
 // Replaces the seed loop of myLineSegmentDetector (LSD/myLSD.cpp:219-272) and its callees
 // RegionGrower (:491-590), CenterGetter/OrientationGetter/RectangleConverter (:592-734),
 // RegionRadiusReducer (:736-802), Refiner (:804-880), LogGammaCalculator (:882-924),
 // RectangleNFACalculator (:926-1059) and RectangleImprover (:1061-1158).
 //
-// The reference semantics are strictly sequential (each seed sees the usedMap left by all earlier
-// ones; inside a region every accepted pixel changes the angle used to test the next), so one image
-// is walked by ONE wavefront and the batch supplies the parallelism (one workgroup per image).
-// Inside the wavefront the lanes cooperate where the order of evaluation can be kept:
-//   * region growing: 8 frontier pixels x 8 neighbours are fetched and angle-tested by 64 lanes,
-//     a ballot gives the first passing candidate in reference order, which is committed, the
-//     region angle is updated and the remaining lanes are re-tested (exactly the reference order);
+// The reference is strictly sequential: seeds are visited in sorted order and each one sees the
+// usedMap left by all earlier ones.  What actually couples two seeds is small, though: a seed's whole
+// evaluation (grow, rectangle, refine, NFA) reads usedMap only through "is this pixel banned
+// (== 1)?", and only ACCEPTED lines ever set a pixel to 1 (rejected regions set 2, which stays
+// growable; small/failed regions set nothing).  So the NW wavefronts of a workgroup evaluate NW
+// consecutive seeds SPECULATIVELY and concurrently, and commit in seed order:
+//   * a wave takes the next seed (LDS counter), notes the accept epoch, drops its tile cache and
+//     evaluates the seed against the current usedMap with its private curMap stamps;
+//   * it then waits for its turn (commit cursor), re-checks that the seed pixel is still unused and
+//     that no line accepted since its snapshot touches the bounding box of what it examined; if one
+//     does, it simply re-evaluates the seed (now non-speculatively: everything earlier is committed);
+//   * commit = mark usedMap (1 or 2), append the rectangle, advance the cursor.
+// The committed sequence of decisions is therefore exactly the sequential one.
+// Inside a wavefront the lanes cooperate where the order of evaluation can be kept:
+//   * region growing: 8 frontier pixels x 8 neighbours per batch, see grow();
 //   * rectangle moments: products per lane, SERIAL accumulation in list order (bit-exact sums);
 //   * NFA pixel count: the rectangle's columns are flattened with a wave prefix sum and counted
 //     with ballot/popcount;
 //   * usedMap marking: only the region's pixels are visited (the reference scans the whole image).
-// curMap is a stamp in the upper 30 bits of the per-pixel state word (no per-call clearing).
 #include "lsd_internal.h"
 #include "devmath.h"
 
 namespace lsdhip {
 
-constexpr int LCAP = 4096;   // region-list entries kept in LDS; the rest spills to HBM
-constexpr int NSLOT = 16;    // tile-cache slots
+constexpr int NW = 4;        // wavefronts (concurrent speculative seeds) per image
+constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
+constexpr int NSLOT = 4;     // tile-cache slots per wave (2 x 2 tiles)
+constexpr int RING = 64;     // remembered bounding boxes of recently accepted lines
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
@@ -34,7 +43,8 @@ struct RCtx {
     int w, h, lane;
     const double* mag;
     const double* deg;
-    uint32_t* state;
+    uint32_t* state;     // usedMap values (shared by the workgroup)
+    uint32_t* stamp;     // this wave's curMap stamps
     uint32_t* spill;
     uint32_t* gcopy;
     const double* sn;
@@ -47,12 +57,13 @@ struct RCtx {
     double* t_sn;        // LDS [NSLOT][64]
     double* t_cs;        // LDS [NSLOT][64]
     int* t_tag;          // LDS [NSLOT]
+    uint32_t* claim;     // LDS [NSLOT][64] first-occurrence arbitration, idle value 0xffffffff
     int tilesX;
     bool dirty;          // stamps stored to HBM since the last fence
     int* s_incl;         // LDS [64]
     int* s_lo;           // LDS [64]
     int* s_x;            // LDS [64]
-    uint32_t cur_id;
+    uint32_t cur_id;     // stamp of the current grow (id_base + running number)
     int gnum;            // size of the last grow (grow order)
     bool has_copy;       // gcopy holds the grow-order list (RegionRadiusReducer reordered lst)
     double logNT;
@@ -60,7 +71,7 @@ struct RCtx {
     const double* ptab;
     long long st_grow, st_grown, st_nfa, st_rrr, st_rrrpass, st_sent, st_oob, st_spill;
     long long t_grow, t_rect, t_nfa, t_mark, st_maxreg, st_nfapx;   // cycle counters (s_memtime) + extremes
-    long long st_exact, st_tilefetch;
+    long long st_exact, st_tilefetch, st_batches, t_tiles, t_chain, t_commit;
 };
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -84,12 +95,12 @@ __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp
 
 // ---------------------------------------------------------------------------------------------
 // LDS tile cache: 8x8-pixel tiles of (state, deg, sin deg, cos deg), direct-mapped over a
-// 64x16-pixel window (slot = tx&7 | (ty&1)<<3).  RegionGrower reads its 3x3 neighbourhoods from
+// 16x16-pixel window (slot = tx&1 | (ty&1)<<1).  RegionGrower reads its 3x3 neighbourhoods from
 // here, so a batch costs LDS latency instead of two dependent HBM round trips plus a store fence.
 // Accepted pixels are stamped in the LDS copy AND in HBM (write-through, never waited for); the
 // cache is dropped whenever usedMap marks change (mark_region).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx & 7) | ((ty & 1) << 3); }
+__device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx & 1) | ((ty & 1) << 1); }
 
 // Makes the tiles of every lane with need==true resident.  Returns false when two needed tiles map
 // to the same slot (the caller retries with a smaller batch; a single 3x3 neighbourhood never conflicts).
@@ -110,6 +121,7 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
             chk &= ~__ballot(tile == T);
         }
     }
+    const long long tt0 = (long long)__builtin_amdgcn_s_memtime();
     if (c.dirty) { wg_fence(); c.dirty = false; }     // earlier stamps must have landed before a tile is (re)read
     c.st_tilefetch++;
     while (todo) {
@@ -137,9 +149,10 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
                 const int x = ttx * 8 + (lane & 7), y = tty * 8 + (lane >> 3);
                 if (x < w && y < h) {
                     const size_t q = (size_t)y * w + x;
-                    vw[j] = c.state[q];
+                    vw[j] = (c.stamp[q] << 2) | (c.state[q] & 3u);
                     vd[j] = c.deg[q];
-                    if ((vw[j] & 3u) != 1u) { vs[j] = c.sn[q]; vc[j] = c.cs[q]; }
+                    vs[j] = c.sn[q];                              // garbage where usedMap == 1: never read
+                    vc[j] = c.cs[q];
                 }
             }
         }
@@ -155,6 +168,7 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
         }
     }
     wg_fence();
+    c.t_tiles += (long long)__builtin_amdgcn_s_memtime() - tt0;
     return true;
 }
 
@@ -167,18 +181,25 @@ __device__ __forceinline__ void invalidate_tiles(RCtx& c) {
 // RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order); returns the size and
 // the angle sums (the region angle atan2(sinS, cosS) is evaluated by the caller only when needed).
 //
-// Exactness: the reference tests every candidate against regDeg = atan2(sinDeg, cosDeg) recomputed
-// after each accepted pixel (:545-547).  Here the sums are accumulated exactly in the reference
-// order, the angle used for the tests is a cheap fp32 estimate with a rigorous error bound, and the
-// correctly rounded angle is computed only for candidates whose test is within that bound of the
-// threshold -- every decision is the one the exact angle would give.
-// Sweeps after the first revisit only the entries that still had a non-member, non-banned
-// neighbour (membership and bans only grow during one call, so the others cannot accept anything).
+// The reference tests every candidate against regDeg = atan2(sinDeg, cosDeg) recomputed after each
+// accepted pixel (:545-547), in list order / row-major neighbour order.  Here a batch of 8 frontier
+// pixels x 8 neighbours is classified at once against an ESTIMATE of regDeg with a rigorous margin:
+//   margin = (error of the fp32 estimate) + (largest drift regDeg can undergo while the up-to-m
+//            candidates of this batch are accepted: each accepted unit vector lies within tol of the
+//            current sum vector of norm L, so it turns it by at most sin(tol)/L)
+//   * |dif| < tol - margin : passes whatever happens earlier in the batch  -> accepted in bulk
+//   * |dif| > tol + margin : fails whatever happens                        -> ignored
+//   * otherwise            : resolved one by one in reference order against a fresh estimate, and
+//                            against the correctly rounded angle when still too close to call.
+// The sums are accumulated in the reference order in every case, so they are bit-identical, and every
+// accept/reject decision is the one the exact angle would give.
+// Sweeps after the first revisit only entries that still had a non-member, non-banned neighbour
+// (membership and bans only grow during one call, so the others cannot accept anything).
 // ---------------------------------------------------------------------------------------------
 constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
 
 __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, double tol, int& out_num,
-                                  double& out_sin, double& out_cos) {
+                                     double& out_sin, double& out_cos) {
     const int lane = c.lane, w = c.w, h = c.h;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     const uint32_t id = ++c.cur_id;                          // fresh curMap (:519)
@@ -190,19 +211,21 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         cosS = c.t_cs[slot * 64 + ti];
         if (lane == 0) {
             lset(c, 0, pack_xy(sx, sy));
-            const uint32_t wd = (id << 2) | (c.t_st[slot * 64 + ti] & 3u);
-            c.t_st[slot * 64 + ti] = wd;                     // :520
-            c.state[(size_t)sy * w + sx] = wd;
+            c.t_st[slot * 64 + ti] = (id << 2) | (c.t_st[slot * 64 + ti] & 3u);   // :520
+            c.stamp[(size_t)sy * w + sx] = id;
         }
         c.dirty = true;
     }
-    double R = regDeg0;                                      // angle used by the tests
-    double eps = 0.0;                                        // 0: R is the exact reference value
+    double R = regDeg0;                                      // angle estimate used by the tests
+    double eps = 0.0;                                        // its error bound; 0: R is the exact reference value
+    bool stale = false;                                      // sums changed since R was computed
+    const bool tol_small = tol < 1.5;                        // accepted vectors then never shorten the sum
+    const double turn = tol < 1.1 ? tol : 1.1;               // >= sin(tol) resp. the asin(1/L)*L bound
     int n = 1;
-    wg_fence();
     const int e = lane >> 3, k = lane & 7;
     const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
     const int ox = kk % 3 - 1, oy = kk / 3 - 1;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
     uint16_t* wl_cur = c.wl0;
     uint16_t* wl_nxt = c.wl1;
     int wl_cnt = 0;                                          // entries of wl_cur (sweep >= 2)
@@ -228,71 +251,101 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                 eidx = i + e;
             }
             bool valid = e < cnt;
-            uint32_t pk = valid ? lget(c, eidx) : 0u;
-            int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+            const uint32_t pk = valid ? lget(c, eidx) : 0u;
+            const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
             bool inb = valid && nx >= 0 && ny >= 0 && nx < w && ny < h;            // :536
-            if (!ensure_tiles(c, inb, nx, ny)) {             // slot conflict: one entry at a time
-                cnt = 1;
-                valid = e < cnt;
-                inb = inb && valid;
-                ensure_tiles(c, inb, nx, ny);
-            }
             const int slot = tile_slot(nx >> 3, ny >> 3), ti = ((ny & 7) << 3) | (nx & 7);
+            const int cell = slot * 64 + ti;
+            if (__ballot(inb && c.t_tag[slot] != (ny >> 3) * c.tilesX + (nx >> 3))) {
+                if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
+                    cnt = 1;
+                    valid = e < cnt;
+                    inb = inb && valid;
+                    ensure_tiles(c, inb, nx, ny);
+                }
+            }
             const int q = ny * w + nx;
-            const uint32_t word = inb ? c.t_st[slot * 64 + ti] : 1u;
+            const uint32_t word = inb ? c.t_st[cell] : 1u;
             const bool cand = inb && (word >> 2) != id && (word & 3u) != 1u;       // :537 (2 is growable, Q5)
-            const double d = cand ? c.t_deg[slot * 64 + ti] : 0.0;
-            unsigned long long rem = __ballot(cand);
-            unsigned long long gone = 0;                     // candidates that became members in this batch
-            while (rem) {
+            const unsigned long long candm = __ballot(cand);
+            unsigned long long acc = 0;                      // accepted lanes (one per accepted pixel)
+            unsigned long long gone = 0;                     // every lane whose pixel became a member in this batch
+            if (candm) {
+                const double d = cand ? c.t_deg[cell] : 0.0;
+                const double sd = cand ? c.t_sn[cell] : 0.0, cd = cand ? c.t_cs[cell] : 0.0;
+                // first occurrence (lowest lane) of every candidate pixel
+                if (cand) atomicMin(&c.claim[cell], (uint32_t)lane);
+                const bool winner = cand && c.claim[cell] == (uint32_t)lane;
+                if (cand) c.claim[cell] = 0xffffffffu;
+                // refresh the estimate once per batch
+                if (stale) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; stale = false; }
+                // margin: estimate error + worst-case drift while this batch's candidates are accepted
+                const int m = __builtin_popcountll(__ballot(winner));
+                const float Lf = sqrtf((float)(sinS * sinS + cosS * cosS));
+                const double Ld = (double)Lf * 0.999 - (tol_small ? 0.0 : (double)m);
+                const double margin = Ld >= (tol_small ? 1.0 : 3.0) ? eps + 1.001 * (double)m * turn / Ld : 1e30;
                 const double raw = fabs(R - d);
                 const double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;  // :540-542
+                const bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
                 bool pc, amb;
-                if (eps == 0.0) { pc = dif < tol; amb = false; }                   // :543
+                if (margin == 0.0) { pc = dif < tol; amb = false; }               // :543 (exact R, nothing can drift)
                 else {
-                    pc = dif < tol - eps;
-                    amb = !pc && !(dif > tol + eps);
-                    if (fabs(raw - kPi * 3 / 2.0) <= eps) { amb = true; pc = false; }
+                    pc = !cut && dif < tol - margin;
+                    amb = cut || (!pc && !(dif > tol + margin));
                 }
-                const unsigned long long m_pc = __ballot(cand && pc) & rem;
-                const unsigned long long m_amb = __ballot(cand && amb) & rem;
-                const unsigned long long first = m_pc | m_amb;
-                if (!first) break;
-                const int l = __builtin_ctzll(first);        // first candidate in reference order that may pass
-                if ((m_amb >> l) & 1ull) {                   // too close to call with the estimate: exact angle
-                    R = atan2_g(sinS, cosS);                 // :547
-                    eps = 0.0;
-                    c.st_exact++;
-                    continue;
+                const unsigned long long P = __ballot(winner && pc);              // accepted whatever the order
+                const unsigned long long A = __ballot(cand && amb);               // every occurrence, resolved in order
+                unsigned long long todo = P | A;
+                c.st_batches++;
+                while (todo) {
+                    const int l = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    bool take = (P >> l) & 1ull;
+                    if (!take) {
+                        if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
+                        const double dl = rl(d, l);
+                        if (stale) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; stale = false; }
+                        double rw = fabs(R - dl);
+                        double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                        if (eps != 0.0 && (fabs(R) > kPi - eps || fabs(df - tol) <= eps || fabs(rw - kPi * 3 / 2.0) <= eps ||
+                                           !(tol == tol))) {
+                            R = atan2_g(sinS, cosS);         // :547, too close to call with the estimate
+                            eps = 0.0;
+                            c.st_exact++;
+                            rw = fabs(R - dl);
+                            df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                        }
+                        take = df < tol;                     // :543
+                    }
+                    if (take) {
+                        cosS += rl(cd, l);                   // :545
+                        sinS += rl(sd, l);                   // :546
+                        stale = true;
+                        acc |= 1ull << l;
+                        if (!((P >> l) & 1ull)) gone |= __ballot(cand && q == __builtin_amdgcn_readlane(q, l));
+                    }
                 }
-                cosS += rl(c.t_cs[slot * 64 + ti], l);       // :545
-                sinS += rl(c.t_sn[slot * 64 + ti], l);       // :546
-                R = (double)atan2f((float)sinS, (float)cosS);
-                eps = kAngEps;
-                const int ql = __builtin_amdgcn_readlane(q, l);
-                if (lane == l) {
-                    const uint32_t wd = (id << 2) | (word & 3u);
-                    c.t_st[slot * 64 + ti] = wd;             // :549
-                    c.state[q] = wd;
-                    lset(c, n, pack_xy(nx, ny));             // :551-556
+                if (acc) {
+                    const bool mine = (acc >> lane) & 1ull;
+                    if (mine) {
+                        c.t_st[cell] = (id << 2) | (word & 3u);   // :549
+                        c.stamp[q] = id;
+                        lset(c, n + __builtin_popcountll(acc & ltmask), pack_xy(nx, ny));   // :551-556
+                    }
+                    n += __builtin_popcountll(acc);
+                    c.dirty = true;
                 }
-                n++;
-                const unsigned long long same = __ballot(cand && q == ql);
-                gone |= same;
-                rem &= ~((2ull << l) - 1ull);                // everything up to l has had its turn
-                rem &= ~same;                                // the same pixel seen from another frontier pixel
-                c.dirty = true;
-            }
-            // entries that still have a growable non-member neighbour go to the next sweep's worklist
-            if (filter) {
-                const unsigned long long left = __ballot(cand) & ~gone;
-                const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
-                const unsigned long long hm = __ballot(has && k == 0);
-                const int add = __builtin_popcountll(hm);
-                if (nxt_cnt + add > LCAP || n > 65535) filter = false;
-                else {
-                    if (has && k == 0) wl_nxt[nxt_cnt + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = (uint16_t)eidx;
-                    nxt_cnt += add;
+                // entries that still have a growable non-member neighbour go to the next sweep's worklist
+                if (filter) {
+                    const unsigned long long left = candm & ~gone & ~__ballot(cand && pc && margin != 1e30 && !amb);
+                    const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
+                    const unsigned long long hm = __ballot(has && k == 0);
+                    const int add = __builtin_popcountll(hm);
+                    if (nxt_cnt + add > LCAP || n > 65535) filter = false;
+                    else {
+                        if (has && k == 0) wl_nxt[nxt_cnt + __builtin_popcountll(hm & ltmask)] = (uint16_t)eidx;
+                        nxt_cnt += add;
+                    }
                 }
             }
             if (in_wl) wi += cnt; else i += cnt;
@@ -437,7 +490,7 @@ __device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num,
             if (sqrt(ddx * ddx + ddy * ddy) > rad) {                               // :780
                 if (lane == 0) {
                     const size_t q = (size_t)py * w + px;
-                    c.state[q] = c.state[q] & 3u;                                  // curMap = 0 (:781)
+                    c.stamp[q] = 0u;                                               // curMap = 0 (:781)
                     if (i == num) { lset(c, num - 1, 0u); }
                     else { lset(c, i, lget(c, num - 1)); lset(c, num - 1, 0u); }   // :782-785
                 }
@@ -664,102 +717,198 @@ __device__ __forceinline__ bool refine(RCtx& c, int sx, int sy, int& num, double
 // ---------------------------------------------------------------------------------------------
 // seed loop, myLSD.cpp:219-272
 // ---------------------------------------------------------------------------------------------
-__device__ void mark_region(RCtx& c, uint32_t val) {   // :243-248 / :259-265 restricted to the grown pixels
+// usedMap marking (:243-248 / :259-265) restricted to the grown pixels; returns their bounding box.
+__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, int& bx0, int& by0, int& bx1, int& by1) {
     const int w = c.w;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     wg_fence();                                   // the stamps written by grow() must have landed
     c.dirty = false;
+    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
     for (int k2 = c.lane; k2 < c.gnum; k2 += 64) {
         const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
-        const size_t q = (size_t)(pkx >> 16) * w + (pkx & 0xffffu);
-        const uint32_t word = c.state[q];
-        if ((word >> 2) == c.cur_id) c.state[q] = (word & ~3u) | val;   // curMap == 1 only
+        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+        const size_t q = (size_t)y * w + x;
+        if (c.stamp[q] == c.cur_id) {             // curMap == 1 only
+            c.state[q] = val;
+            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+        }
     }
-    wg_fence();
-    invalidate_tiles(c);                          // cached usedMap bits are stale now
+    for (int off = 32; off >= 1; off >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+    }
+    bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
     c.t_mark += (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
-__global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
-    __shared__ uint32_t lst[LCAP];
-    __shared__ uint16_t wl0[LCAP], wl1[LCAP];
-    __shared__ double t_deg[NSLOT * 64], t_sn[NSLOT * 64], t_cs[NSLOT * 64];
-    __shared__ uint32_t t_st[NSLOT * 64];
-    __shared__ int t_tag[NSLOT];
-    __shared__ int s_incl[64], s_lo[64], s_x[64];
+// bounding box of the pixels currently in the region list
+__device__ __forceinline__ void list_bbox(const RCtx& c, int num, int& bx0, int& by0, int& bx1, int& by1) {
+    int x0 = bx0, y0 = by0, x1 = bx1, y1 = by1;
+    for (int k2 = c.lane; k2 < num; k2 += 64) {
+        const uint32_t pkx = lget(c, k2);
+        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+        x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+    }
+    bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
+}
+
+__device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t id_base) {
+    __shared__ uint32_t lst[NW][LCAP];
+    __shared__ uint16_t wl0[NW][LCAP], wl1[NW][LCAP];
+    __shared__ double t_deg[NW][NSLOT * 64], t_sn[NW][NSLOT * 64], t_cs[NW][NSLOT * 64];
+    __shared__ uint32_t t_st[NW][NSLOT * 64];
+    __shared__ uint32_t claim[NW][NSLOT * 64];
+    __shared__ int t_tag[NW][NSLOT];
+    __shared__ int s_incl[NW][64], s_lo[NW][64], s_x[NW][64];
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds;
+    __shared__ short s_ring[RING][4];
+
     const size_t img = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = g.w, h = g.h;
     const size_t npx = (size_t)g.npx;
 
     RCtx c;
     c.w = w; c.h = h; c.lane = lane;
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.state = b.state + img * npx;
-    c.spill = b.spill + img * npx; c.gcopy = b.gcopy + img * npx;
-    c.lst = lst; c.s_incl = s_incl; c.s_lo = s_lo; c.s_x = s_x;
     c.sn = b.sn + img * npx; c.cs = b.cs + img * npx;
-    c.wl0 = wl0; c.wl1 = wl1; c.t_st = t_st; c.t_deg = t_deg; c.t_sn = t_sn; c.t_cs = t_cs; c.t_tag = t_tag;
-    c.tilesX = (w + 7) >> 3; c.dirty = false; c.st_exact = 0; c.st_tilefetch = 0;
-    if (lane < NSLOT) t_tag[lane] = -1;
-    wg_fence();
-    c.cur_id = 0; c.gnum = 0; c.has_copy = false;
+    c.stamp = b.stamps + (img * NW + wave) * npx;
+    c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
+    c.lst = lst[wave]; c.wl0 = wl0[wave]; c.wl1 = wl1[wave];
+    c.t_st = t_st[wave]; c.t_deg = t_deg[wave]; c.t_sn = t_sn[wave]; c.t_cs = t_cs[wave]; c.t_tag = t_tag[wave];
+    c.claim = claim[wave]; c.s_incl = s_incl[wave]; c.s_lo = s_lo[wave]; c.s_x = s_x[wave];
+    c.tilesX = (w + 7) >> 3; c.dirty = false;
+    c.cur_id = id_base; c.gnum = 0; c.has_copy = false;
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
     c.st_grow = c.st_grown = c.st_nfa = c.st_rrr = c.st_rrrpass = c.st_sent = c.st_oob = c.st_spill = 0;
     c.t_grow = c.t_rect = c.t_nfa = c.t_mark = c.st_maxreg = c.st_nfapx = 0;
+    c.st_exact = c.st_tilefetch = c.st_batches = c.t_tiles = c.t_chain = c.t_commit = 0;
+    long long st_redo = 0, st_discard = 0, t_wait = 0;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+    for (int j = lane; j < NSLOT * 64; j += 64) c.claim[j] = 0xffffffffu;
+    if (lane < NSLOT) c.t_tag[lane] = -1;
 
     const uint32_t* ord = b.ord + img * npx;
+    uint32_t* seedidx = b.seedidx + img * npx;
     const int nb = b.nb[img];
     double* recs = b.recs + img * (size_t)b.max_lines * 12;
     double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
     SeedRec* trace = b.seeds ? reinterpret_cast<SeedRec*>(b.seeds) + img * npx : nullptr;
-    int ntrace = 0, cntLines = 0;
-    int epoch = 0;
 
-    for (int base = 0; base < nb; base += 64) {
-        const int idx = base + lane;
-        const uint32_t p = idx < nb ? ord[idx] : 0u;
-        const uint32_t wd0 = idx < nb ? c.state[p] : 1u;
-        unsigned long long m = __ballot(idx < nb && (wd0 & 3u) == 0u);               // :222
-        const int epoch0 = epoch;
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)p, l);
-            if (epoch != epoch0) {                      // a region was marked since the chunk was loaded
-                const uint32_t wd = c.state[pp];
-                if ((wd & 3u) != 0u) continue;
-            }
-            const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
-            int num; double regdeg, gs, gc;
-            const double seedDeg = c.deg[pp];
-            grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                         // :225
-            SeedRec tr;
-            tr.order_idx = base + l; tr.x = sx; tr.y = sy; tr.num = num; tr.outcome = 0; tr.final_num = num;
-            tr.logNFA = 0;
-            bool done = false;
-            Rec rec;
-            if (num < g.regThre) done = true;                                        // :228 (not marked, Q5)
-            if (!done) {
-                regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                         // reg.deg (:547, :581)
-                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232
-                const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);      // :234
-                tr.final_num = num;
-                if (!ok) { tr.outcome = 1; done = true; }                            // :237
-            }
-            if (!done) {
-                const double logNFA = improve(c, rec);                               // :240
-                tr.logNFA = logNFA;
-                if (logNFA <= 0) {                                                   // :242-250
-                    mark_region(c, 2u);
-                    epoch++;
-                    tr.outcome = 2;
-                    done = true;
+    // potential seeds: sorted entries whose pixel is not below the gradient threshold (usedMap == 0 after K2)
+    if (wave == 0) {
+        int cnt = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int base = 0; base < nb; base += 64) {
+            const int idx = base + lane;
+            const bool ok = idx < nb && (c.state[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
+            const unsigned long long m = __ballot(ok);
+            if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
+            cnt += __builtin_popcountll(m);
+        }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; }
+        wg_fence();
+    }
+    __syncthreads();
+    const int nseeds = s_nseeds;
+
+    while (true) {
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&s_next, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= nseeds) break;
+        const int oidx = (int)seedidx[k];
+        const uint32_t pp = ord[oidx];
+        const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
+
+        bool skip = false;
+        int outcome = 0, num = 0, num0 = 0;
+        double logNFA = 0;
+        Rec rec;
+        int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const int epoch_snap = lds_ld(&s_epoch);      // before anything of usedMap is read for this seed
+            wg_fence();
+            invalidate_tiles(c);
+            skip = (c.state[pp] & 3u) != 0u;              // monotone: once used, always used (:222)
+            outcome = 0; logNFA = 0;
+            fx0 = fy0 = 0x7fffffff; fx1 = fy1 = -1;
+            if (!skip) {
+                double regdeg, gs, gc;
+                const double seedDeg = c.deg[pp];
+                grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                     // :225
+                num0 = num;
+                bool done = num < g.regThre;                                          // :228 (not marked, Q5)
+                if (!done) {
+                    regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                     // reg.deg (:547, :581)
+                    rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);        // :232
+                    if (rec_density(num, rec) < g.denThre) list_bbox(c, num, fx0, fy0, fx1, fy1);   // refine() will regrow
+                    const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);   // :234
+                    if (!ok) { outcome = 1; done = true; }                            // :237
+                }
+                if (!done) {
+                    logNFA = improve(c, rec);                                         // :240
+                    outcome = logNFA <= 0 ? 2 : 3;                                    // :242
                 }
             }
-            if (!done) {
-                if (cntLines < b.max_lines && lane == 0) {
-                    double* rr = recs + (size_t)cntLines * 12;
+            if (attempt == 0) {                           // wait for this seed's turn to commit
+                const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
+                while (lds_ld(&s_commit) != k) __builtin_amdgcn_s_sleep(4);
+                wg_fence();
+                t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            }
+            if (skip) break;
+            if ((c.state[pp] & 3u) != 0u) { skip = true; st_discard++; break; }   // an earlier seed marked it meanwhile
+            const int epoch_now = lds_ld(&s_epoch);
+            if (attempt == 1 || epoch_now == epoch_snap) break;
+            // lines accepted since the snapshot: did any of them touch what this evaluation examined?
+            bool conflict = epoch_now - epoch_snap > RING;
+            if (!conflict) {
+                int x0 = fx0, y0 = fy0, x1 = fx1, y1 = fy1;
+                if (c.has_copy) {                         // RegionRadiusReducer reordered/shrunk lst: use the grow-order copy
+                    for (int k2 = lane; k2 < c.gnum; k2 += 64) {
+                        const uint32_t pkx = c.gcopy[k2];
+                        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+                        x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+                    }
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+                        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+                    }
+                } else list_bbox(c, c.gnum, x0, y0, x1, y1);
+                x0 -= 1; y0 -= 1; x1 += 1; y1 += 1;       // the 8-neighbourhoods that were examined
+                for (int ep = epoch_snap; ep < epoch_now; ep++) {
+                    const short* r = s_ring[ep & (RING - 1)];
+                    if (!(r[2] < x0 || r[0] > x1 || r[3] < y0 || r[1] > y1)) conflict = true;
+                }
+            }
+            if (!conflict) break;
+            st_redo++;                                    // evaluate again, now with everything earlier committed
+        }
+
+        // ---- commit (in seed order) ----
+        if (!skip) {
+            if (trace && lane == 0) {
+                SeedRec tr;
+                tr.order_idx = oidx; tr.x = sx; tr.y = sy; tr.num = num0; tr.outcome = outcome;
+                tr.final_num = outcome == 0 ? num0 : num; tr.logNFA = logNFA;
+                trace[s_ntrace] = tr;
+            }
+            if (lane == 0) s_ntrace = s_ntrace + 1;
+            int bx0, by0, bx1, by1;
+            if (outcome == 2) {                                                      // :242-250
+                mark_region(c, 2u, bx0, by0, bx1, by1);
+            } else if (outcome == 3) {
+                const int li = s_lines;
+                if (li < b.max_lines && lane == 0) {
+                    double* rr = recs + (size_t)li * 12;
                     rr[0] = rec.x1; rr[1] = rec.y1; rr[2] = rec.x2; rr[3] = rec.y2; rr[4] = rec.wid; rr[5] = rec.cX;
                     rr[6] = rec.cY; rr[7] = rec.deg; rr[8] = rec.dx; rr[9] = rec.dy; rr[10] = rec.p; rr[11] = rec.prec;
                     double x1 = rec.x1, y1 = rec.y1, x2 = rec.x2, y2 = rec.y2;
@@ -767,34 +916,50 @@ __global__ __launch_bounds__(64) void k_region(Geom g, Buffers b) {
                         x1 = (x1 - 1.0) / g.sca + 1; y1 = (y1 - 1.0) / g.sca + 1;
                         x2 = (x2 - 1.0) / g.sca + 1; y2 = (y2 - 1.0) / g.sca + 1;
                     }
-                    double* rs = recs_scaled + (size_t)cntLines * 4;
+                    double* rs = recs_scaled + (size_t)li * 4;
                     rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
                 }
-                cntLines++;
-                mark_region(c, 1u);                                                  // :259-265
-                epoch++;
-                tr.outcome = 3;
+                mark_region(c, 1u, bx0, by0, bx1, by1);                              // :259-265
+                wg_fence();                               // the marks must be visible before the epoch moves
+                if (lane == 0) {
+                    const int ep = s_epoch;
+                    short* r = s_ring[ep & (RING - 1)];
+                    r[0] = (short)bx0; r[1] = (short)by0; r[2] = (short)bx1; r[3] = (short)by1;
+                    s_lines = li + 1;
+                    lds_st(&s_epoch, ep + 1);
+                }
             }
-            if (trace && lane == 0) trace[ntrace] = tr;
-            ntrace++;
         }
+        wg_fence();                                       // marks + ring visible before the cursor moves
+        if (lane == 0) lds_st(&s_commit, k + 1);
     }
-    if (lane == 0) {
-        b.counts[img] = cntLines;
-        if (b.nseed) b.nseed[img] = ntrace;
-        if (b.stats) {
-            long long* st = b.stats + img * 24;
-            st[16] = c.st_exact; st[17] = c.st_tilefetch;
-            st[0] = c.st_grow; st[1] = c.st_grown; st[2] = c.st_nfa; st[3] = c.st_rrr; st[4] = c.st_rrrpass;
-            st[5] = c.st_sent; st[6] = c.st_oob; st[7] = c.st_spill;
-            st[8] = (long long)__builtin_amdgcn_s_memtime() - t_begin; st[9] = c.t_grow; st[10] = c.t_rect;
-            st[11] = c.t_nfa; st[12] = c.t_mark; st[13] = c.st_maxreg; st[14] = c.st_nfapx; st[15] = ntrace;
-        }
+
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b.counts[img] = s_lines;
+        if (b.nseed) b.nseed[img] = s_ntrace;
+    }
+    if (lane == 0 && b.stats) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 24);
+        atomicAdd(&st[0], (unsigned long long)c.st_grow); atomicAdd(&st[1], (unsigned long long)c.st_grown);
+        atomicAdd(&st[2], (unsigned long long)c.st_nfa); atomicAdd(&st[3], (unsigned long long)c.st_rrr);
+        atomicAdd(&st[4], (unsigned long long)c.st_rrrpass); atomicAdd(&st[5], (unsigned long long)c.st_sent);
+        atomicAdd(&st[6], (unsigned long long)c.st_oob); atomicAdd(&st[7], (unsigned long long)c.st_spill);
+        if (wave == 0) { st[8] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); st[15] = (unsigned long long)nseeds; }
+        atomicAdd(&st[9], (unsigned long long)c.t_grow); atomicAdd(&st[10], (unsigned long long)c.t_rect);
+        atomicAdd(&st[11], (unsigned long long)c.t_nfa); atomicAdd(&st[12], (unsigned long long)c.t_mark);
+        atomicMax(&st[13], (unsigned long long)c.st_maxreg); atomicAdd(&st[14], (unsigned long long)c.st_nfapx);
+        atomicAdd(&st[16], (unsigned long long)c.st_exact); atomicAdd(&st[17], (unsigned long long)c.st_tilefetch);
+        atomicAdd(&st[18], (unsigned long long)c.st_batches); atomicAdd(&st[19], (unsigned long long)c.t_tiles);
+        atomicAdd(&st[20], (unsigned long long)st_redo); atomicAdd(&st[21], (unsigned long long)st_discard);
+        atomicAdd(&st[22], (unsigned long long)t_wait);
     }
 }
 
-void launch_region(const Geom& g, const Buffers& b, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_region, dim3(n), dim3(64), 0, s, g, b);
+void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
+    hipLaunchKernelGGL(k_region, dim3(n), dim3(64 * NW), 0, s, g, b, id_base);
 }
+
+int region_waves() { return NW; }
 
 }  // namespace lsdhip

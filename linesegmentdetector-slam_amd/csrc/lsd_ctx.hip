@@ -29,7 +29,8 @@ struct lsd_ctx {
     // workspace
     double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *sn = nullptr, *cs = nullptr, *recs = nullptr,
            *recs_scaled = nullptr;
-    uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr;
+    uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
+    uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
@@ -172,7 +173,11 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
         HIPCHK(c, re_alloc(&c->sn, tot)); HIPCHK(c, re_alloc(&c->cs, tot));
         HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
-        HIPCHK(c, re_alloc(&c->spill, tot)); HIPCHK(c, re_alloc(&c->gcopy, tot));
+        const size_t nwv = (size_t)region_waves();
+        HIPCHK(c, re_alloc(&c->spill, tot * nwv)); HIPCHK(c, re_alloc(&c->gcopy, tot * nwv));
+        HIPCHK(c, re_alloc(&c->stamps, tot * nwv)); HIPCHK(c, re_alloc(&c->seedidx, tot));
+        HIPCHK(c, hipMemset(c->stamps, 0, tot * nwv * sizeof(uint32_t)));
+        c->run_id = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * 24));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
@@ -246,7 +251,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -297,7 +302,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
-    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy;
+    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.stamps = c->stamps; b.seedidx = c->seedidx;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
@@ -316,7 +321,15 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) launch_sort(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
-    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) launch_region(g, b, n, s);
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
+        // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
+        if (++c->run_id >= 1023u) {
+            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_n * c->cap_npx * (size_t)region_waves() * sizeof(uint32_t), s));
+            c->run_id = 1;
+        }
+        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 24 * n, s));
+        launch_region(g, b, n, c->run_id << 20, s);
+    }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     if (c->stop_after == 0) launch_lines(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[5], s));

@@ -37,13 +37,15 @@ struct Buffers {
     double* deg;           // n x npx
     double* sn;            // n x npx : sin(deg), written where usedMap == 0 after the gradient pass
     double* cs;            // n x npx : cos(deg), same
-    uint32_t* state;       // n x npx : (curMap stamp << 2) | usedMap value
+    uint32_t* state;       // n x npx : usedMap value
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
     uint16_t* ordv;        // n x npx : bin values
-    uint32_t* spill;       // n x npx : region list beyond the LDS part
-    uint32_t* gcopy;       // n x npx : grow-order copy used when RegionRadiusReducer reorders the list
+    uint32_t* stamps;      // n x NW x npx : per-wave curMap stamps of the region stage
+    uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
+    uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
+    uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
     int32_t* counts;       // n
@@ -70,7 +72,8 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
-void launch_region(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
+int region_waves();
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 

@@ -25,6 +25,6 @@ for n in ns:
     st = ctx.fetch(0, lsd.DBG_STATS, lsd.scaled_size(size, size))
     print(n, {k: round(v, 3) for k, v in t.items()}, int(counts[:n].sum()), flush=True)
     if n == ns[-1]:
-        for i in range(min(n, 16)):
+        for i in range(min(n, 6)):
             st = ctx.fetch(i, lsd.DBG_STATS, lsd.scaled_size(size, size))
             print(i, int(counts[i]), {k: (v // 1000 if k.startswith('cycles') else v) for k, v in st.items()}, flush=True)
