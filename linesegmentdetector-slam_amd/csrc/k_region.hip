@@ -756,8 +756,27 @@ __device__ __forceinline__ void list_bbox(const RCtx& c, int num, int& bx0, int&
     bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
 }
 
-__device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Commit ring: one record per seed in flight (index = seed number & (RW-1)).
+//   R_EMPTY  not evaluated yet, or evaluated with a result that marks usedMap ("heavy": its owner keeps it
+//            in registers and commits it itself when the cursor reaches it)
+//   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
+//   R_LIGHT  evaluated, no marks to make (small region :228 or refine failed :237); whoever advances the
+//            cursor checks that no line accepted since the record's snapshot touches its box
+//   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
+//   R_BUSY   being re-evaluated at the cursor
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4 };
+constexpr int RW = 256;
+
+struct Ring {
+    int state[RW];
+    int snap[RW];
+    short box[RW][4];
+    int num0[RW];
+    int numo[RW];        // (final_num << 2) | outcome
+};
 
 __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t id_base) {
     __shared__ uint32_t lst[NW][LCAP];
@@ -767,8 +786,9 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
     __shared__ uint32_t claim[NW][NSLOT * 64];
     __shared__ int t_tag[NW][NSLOT];
     __shared__ int s_incl[NW][64], s_lo[NW][64], s_x[NW][64];
-    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds;
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
+    __shared__ Ring rg;
 
     const size_t img = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -794,6 +814,7 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
     for (int j = lane; j < NSLOT * 64; j += 64) c.claim[j] = 0xffffffffu;
     if (lane < NSLOT) c.t_tag[lane] = -1;
+    for (int j = threadIdx.x; j < RW; j += 64 * NW) rg.state[j] = R_EMPTY;
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
@@ -813,95 +834,202 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
             if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; }
         wg_fence();
     }
     __syncthreads();
     const int nseeds = s_nseeds;
 
+    // box overlap of record-style boxes against the lines accepted in epochs [snap, now)
+    auto hit_since = [&](int snap, int now, int x0, int y0, int x1, int y1) -> bool {
+        if (now - snap > RING) return true;
+        bool hit = false;
+        for (int ep = snap; ep < now; ep++) {
+            const short* r = s_ring[ep & (RING - 1)];
+            if (!(r[2] < x0 || r[0] > x1 || r[3] < y0 || r[1] > y1)) hit = true;
+        }
+        return hit;
+    };
+    auto write_trace = [&](int k, int num0, int fnum, int outcome, double logNFA) {
+        if (lane == 0) {
+            if (trace) {
+                const int oidx = (int)seedidx[k];
+                const uint32_t pp = ord[oidx];
+                SeedRec tr;
+                tr.order_idx = oidx; tr.x = (int)(pp % (uint32_t)w); tr.y = (int)(pp / (uint32_t)w);
+                tr.num = num0; tr.outcome = outcome; tr.final_num = fnum; tr.logNFA = logNFA;
+                trace[s_ntrace] = tr;
+            }
+            s_ntrace = s_ntrace + 1;
+        }
+    };
+    // Moves the commit cursor over finished records (one wave at a time).
+    auto advance = [&]() {
+        int got = 0;
+        if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0 ? 1 : 0;
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (!got) return;
+        while (true) {
+            const int f = lds_ld(&s_commit);
+            if (f >= nseeds) break;
+            const int st = lds_ld(&rg.state[f & (RW - 1)]);
+            if (st == R_SKIP) {
+                if (lane == 0) { rg.state[f & (RW - 1)] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                continue;
+            }
+            if (st == R_LIGHT) {
+                const int snap = rg.snap[f & (RW - 1)], now = lds_ld(&s_epoch);
+                const short* bx = rg.box[f & (RW - 1)];
+                if (now != snap && hit_since(snap, now, bx[0], bx[1], bx[2], bx[3])) {
+                    if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
+                    break;
+                }
+                bool used_now = false;
+                if (trace) used_now = (c.state[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
+                if (!used_now) {
+                    const int no = rg.numo[f & (RW - 1)];
+                    write_trace(f, rg.num0[f & (RW - 1)], no >> 2, no & 3, 0.0);
+                }
+                if (lane == 0) { rg.state[f & (RW - 1)] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                continue;
+            }
+            break;
+        }
+        if (lane == 0) lds_st(&s_lock, 0);
+    };
+
+    int forced_k = -1;                                     // seed to (re)evaluate non-speculatively at the cursor
     while (true) {
-        int k = 0;
-        if (lane == 0) k = atomicAdd(&s_next, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= nseeds) break;
+        // ---- choose the next job ----
+        int k;
+        bool spec;
+        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; }
+        else {
+            // a record waiting to be redone at the cursor has priority
+            const int f = lds_ld(&s_commit);
+            int won = 0;
+            if (f < nseeds && lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) {
+                if (lane == 0) won = atomicCAS(&rg.state[f & (RW - 1)], R_REDO, R_BUSY) == R_REDO ? 1 : 0;
+                won = __builtin_amdgcn_readfirstlane(won);
+            }
+            if (won) { k = f; spec = false; }
+            else {
+                if (lds_ld(&s_next) >= nseeds) {           // nothing left to hand out: help until everything is committed
+                    advance();
+                    if (lds_ld(&s_commit) >= nseeds) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    continue;
+                }
+                if (lds_ld(&s_next) - f >= RW - NW) {      // run-ahead window full
+                    advance();
+                    __builtin_amdgcn_s_sleep(8);
+                    continue;
+                }
+                k = 0;
+                if (lane == 0) k = atomicAdd(&s_next, 1);
+                k = __builtin_amdgcn_readfirstlane(k);
+                if (k >= nseeds) continue;
+                spec = true;
+            }
+        }
         const int oidx = (int)seedidx[k];
         const uint32_t pp = ord[oidx];
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
-        bool skip = false;
+        // ---- evaluate ----
+        const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
+        wg_fence();
+        invalidate_tiles(c);
+        const bool skip = (c.state[pp] & 3u) != 0u;       // monotone: once used, always used (:222)
         int outcome = 0, num = 0, num0 = 0;
         double logNFA = 0;
         Rec rec;
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
-        for (int attempt = 0; attempt < 2; attempt++) {
-            const int epoch_snap = lds_ld(&s_epoch);      // before anything of usedMap is read for this seed
-            wg_fence();
-            invalidate_tiles(c);
-            skip = (c.state[pp] & 3u) != 0u;              // monotone: once used, always used (:222)
-            outcome = 0; logNFA = 0;
-            fx0 = fy0 = 0x7fffffff; fx1 = fy1 = -1;
-            if (!skip) {
-                double regdeg, gs, gc;
-                const double seedDeg = c.deg[pp];
-                grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                     // :225
-                num0 = num;
-                bool done = num < g.regThre;                                          // :228 (not marked, Q5)
-                if (!done) {
-                    regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                     // reg.deg (:547, :581)
-                    rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);        // :232
-                    if (rec_density(num, rec) < g.denThre) list_bbox(c, num, fx0, fy0, fx1, fy1);   // refine() will regrow
-                    const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);   // :234
-                    if (!ok) { outcome = 1; done = true; }                            // :237
-                }
-                if (!done) {
-                    logNFA = improve(c, rec);                                         // :240
-                    outcome = logNFA <= 0 ? 2 : 3;                                    // :242
-                }
+        if (!skip) {
+            double regdeg, gs, gc;
+            const double seedDeg = c.deg[pp];
+            grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                         // :225
+            num0 = num;
+            bool done = num < g.regThre;                                              // :228 (not marked, Q5)
+            if (!done) {
+                regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                         // reg.deg (:547, :581)
+                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232
+                if (spec && rec_density(num, rec) < g.denThre) list_bbox(c, num, fx0, fy0, fx1, fy1);   // refine() will regrow
+                const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);       // :234
+                if (!ok) { outcome = 1; done = true; }                                // :237
             }
-            if (attempt == 0) {                           // wait for this seed's turn to commit
-                const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
-                while (lds_ld(&s_commit) != k) __builtin_amdgcn_s_sleep(4);
-                wg_fence();
-                t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            if (!done) {
+                logNFA = improve(c, rec);                                             // :240
+                outcome = logNFA <= 0 ? 2 : 3;                                        // :242
             }
-            if (skip) break;
-            if ((c.state[pp] & 3u) != 0u) { skip = true; st_discard++; break; }   // an earlier seed marked it meanwhile
-            const int epoch_now = lds_ld(&s_epoch);
-            if (attempt == 1 || epoch_now == epoch_snap) break;
-            // lines accepted since the snapshot: did any of them touch what this evaluation examined?
-            bool conflict = epoch_now - epoch_snap > RING;
-            if (!conflict) {
-                int x0 = fx0, y0 = fy0, x1 = fx1, y1 = fy1;
-                if (c.has_copy) {                         // RegionRadiusReducer reordered/shrunk lst: use the grow-order copy
-                    for (int k2 = lane; k2 < c.gnum; k2 += 64) {
-                        const uint32_t pkx = c.gcopy[k2];
-                        const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
-                        x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
-                    }
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
-                        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
-                    }
-                } else list_bbox(c, c.gnum, x0, y0, x1, y1);
-                x0 -= 1; y0 -= 1; x1 += 1; y1 += 1;       // the 8-neighbourhoods that were examined
-                for (int ep = epoch_snap; ep < epoch_now; ep++) {
-                    const short* r = s_ring[ep & (RING - 1)];
-                    if (!(r[2] < x0 || r[0] > x1 || r[3] < y0 || r[1] > y1)) conflict = true;
-                }
-            }
-            if (!conflict) break;
-            st_redo++;                                    // evaluate again, now with everything earlier committed
         }
 
-        // ---- commit (in seed order) ----
-        if (!skip) {
-            if (trace && lane == 0) {
-                SeedRec tr;
-                tr.order_idx = oidx; tr.x = sx; tr.y = sy; tr.num = num0; tr.outcome = outcome;
-                tr.final_num = outcome == 0 ? num0 : num; tr.logNFA = logNFA;
-                trace[s_ntrace] = tr;
+        // ---- hand the result over ----
+        if (spec) {
+            if (skip) {
+                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
+                advance();
+                continue;
             }
-            if (lane == 0) s_ntrace = s_ntrace + 1;
+            // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
+            int x0 = fx0, y0 = fy0, x1 = fx1, y1 = fy1;
+            if (c.has_copy) {                              // RegionRadiusReducer reordered/shrunk lst: use the grow-order copy
+                for (int k2 = lane; k2 < c.gnum; k2 += 64) {
+                    const uint32_t pkx = c.gcopy[k2];
+                    const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+                    x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+                }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+                    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+                }
+            } else list_bbox(c, c.gnum, x0, y0, x1, y1);
+            x0 -= 1; y0 -= 1; x1 += 1; y1 += 1;
+            if (outcome <= 1) {                            // nothing to mark: publish and move on
+                if (lane == 0) {
+                    const int r = k & (RW - 1);
+                    rg.snap[r] = epoch_snap;
+                    rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
+                    rg.num0[r] = num0; rg.numo[r] = (num << 2) | outcome;
+                    lds_st(&rg.state[r], R_LIGHT);
+                }
+                advance();
+                continue;
+            }
+            // marks to make: keep the result and wait for this seed's turn
+            const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
+            bool abandon = false;
+            while (true) {
+                advance();
+                const int f = lds_ld(&s_commit);
+                if (f == k) break;
+                if (lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) { abandon = true; break; }   // somebody has to redo f: me
+                __builtin_amdgcn_s_sleep(4);
+            }
+            t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            if (abandon) {                                 // give up this result; it is re-evaluated when the cursor gets here
+                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
+                st_redo++;
+                continue;
+            }
+            wg_fence();
+            bool bad = (c.state[pp] & 3u) != 0u;           // an earlier seed marked the pixel meanwhile
+            if (bad) {
+                st_discard++;
+                if (lane == 0) { lds_st(&s_commit, k + 1); }
+                continue;
+            }
+            const int now = lds_ld(&s_epoch);
+            if (now != epoch_snap && hit_since(epoch_snap, now, x0, y0, x1, y1)) {
+                st_redo++;
+                forced_k = k;                              // evaluate again; everything earlier is committed now
+                continue;
+            }
+        }
+
+        // ---- commit at the cursor (k == s_commit, nobody else can commit) ----
+        if (!skip) {
+            write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             int bx0, by0, bx1, by1;
             if (outcome == 2) {                                                      // :242-250
                 mark_region(c, 2u, bx0, by0, bx1, by1);
@@ -931,7 +1059,7 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
             }
         }
         wg_fence();                                       // marks + ring visible before the cursor moves
-        if (lane == 0) lds_st(&s_commit, k + 1);
+        if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
     }
 
     __syncthreads();
