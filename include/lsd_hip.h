@@ -121,7 +121,7 @@ int lsd_set_trace(lsd_ctx *ctx, int on);
  *   RECS           count*12 doubles accepted structRec before rescale (x1 y1 x2 y2 wid cX cY deg dx dy p prec)
  *   SEEDS          n_seed records {int order_idx, x, y, num, outcome, final_num; double logNFA}
  *   NSEED          1 int32
- *   STATS          24 int64         grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, list_spills,
+ *   STATS          32 int64         grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, list_spills,
  *                                   cycles_total, cycles_grow, cycles_rect, cycles_nfa, cycles_mark, max_region, nfa_px, seeds,
  *                                   exact_angle_evals, tile_fetches, batches, cycles_tiles, spec_redos, spec_discards, cycles_wait, (1 reserved)
  *                                   (counters are summed over the wavefronts that share an image)

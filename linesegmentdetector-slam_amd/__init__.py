@@ -59,7 +59,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("LSD_HIP_LIB") or LIB_PATH      # LSD_HIP_LIB: developer A/B builds
     try:
         # torch bundles its own libamdhip64.so.7; when torch is used in the same process (device buffers,
         # streams, RCCL) it must be the HIP runtime that gets loaded first, or the two runtimes clash.
@@ -227,11 +227,12 @@ class Context:
         if what == DBG_ORDER_VAL:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
-            v = get(what, np.int64, 24)
+            v = get(what, np.int64, 32)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                              "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
                              "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait"),
+                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "_r23",
+                             "pt_pick", "pt_reads", "pt_classify", "pt_chain", "pt_commit", "pt_worklist", "all_batches", "_r31"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)

@@ -29,7 +29,13 @@
 
 namespace lsdhip {
 
-constexpr int NW = 4;        // wavefronts (concurrent speculative seeds) per image
+#ifndef LSD_REGION_NW
+#define LSD_REGION_NW 4
+#endif
+#ifndef LSD_REGION_WAVES_PER_SIMD
+#define LSD_REGION_WAVES_PER_SIMD 2
+#endif
+constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
 constexpr int NSLOT = 4;     // tile-cache slots per wave (2 x 2 tiles)
 constexpr int RING = 64;     // remembered bounding boxes of recently accepted lines
@@ -57,7 +63,6 @@ struct RCtx {
     double* t_sn;        // LDS [NSLOT][64]
     double* t_cs;        // LDS [NSLOT][64]
     int* t_tag;          // LDS [NSLOT]
-    uint32_t* claim;     // LDS [NSLOT][64] first-occurrence arbitration, idle value 0xffffffff
     int tilesX;
     bool dirty;          // stamps stored to HBM since the last fence
     int* s_incl;         // LDS [64]
@@ -69,10 +74,13 @@ struct RCtx {
     double logNT;
     const double* lgamma;
     const double* ptab;
-    long long st_grow, st_grown, st_nfa, st_rrr, st_rrrpass, st_sent, st_oob, st_spill;
-    long long t_grow, t_rect, t_nfa, t_mark, st_maxreg, st_nfapx;   // cycle counters (s_memtime) + extremes
-    long long st_exact, st_tilefetch, st_batches, t_tiles, t_chain, t_commit;
+    unsigned long long* stat;   // LDS [32] per-wave counters (see ST_* below); kept out of registers
 };
+
+enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_SPILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
+       ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
+       ST_WAIT, ST_R23, ST_PT0, ST_PT1, ST_PT2, ST_PT3, ST_PT4, ST_PT5, ST_ALLBATCHES, ST_R31, ST_COUNT };
+#define STAT(i, v) do { if (c.lane == 0) c.stat[i] += (unsigned long long)(v); } while (0)
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
@@ -123,7 +131,7 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
     }
     const long long tt0 = (long long)__builtin_amdgcn_s_memtime();
     if (c.dirty) { wg_fence(); c.dirty = false; }     // earlier stamps must have landed before a tile is (re)read
-    c.st_tilefetch++;
+    STAT(ST_TILEFETCH, 1);
     while (todo) {
         // up to 4 missing tiles per round, all loads in flight together
         int T[4], S[4];
@@ -168,7 +176,7 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
         }
     }
     wg_fence();
-    c.t_tiles += (long long)__builtin_amdgcn_s_memtime() - tt0;
+    STAT(ST_TTILES, (long long)__builtin_amdgcn_s_memtime() - tt0);
     return true;
 }
 
@@ -196,6 +204,12 @@ __device__ __forceinline__ void invalidate_tiles(RCtx& c) {
 // Sweeps after the first revisit only entries that still had a non-member, non-banned neighbour
 // (membership and bans only grow during one call, so the others cannot accept anything).
 // ---------------------------------------------------------------------------------------------
+#ifdef LSD_PROFILE_GROW
+#define PT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT(ST_PT0 + (i), t_ - tp); tp = t_; } while (0)
+#else
+#define PT(i) do {} while (0)
+#endif
+
 constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
 
 __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, double tol, int& out_num,
@@ -216,11 +230,18 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         }
         c.dirty = true;
     }
-    double R = regDeg0;                                      // angle estimate used by the tests
-    double eps = 0.0;                                        // its error bound; 0: R is the exact reference value
-    bool stale = false;                                      // sums changed since R was computed
+    // R estimates the reference's regDeg; |R - regDeg| <= eps at any time.  eps is 0 while R is the exact
+    // value, kAngEps right after an fp32 refresh, and grows by the worst-case turn of every pixel accepted
+    // since (so the estimate is refreshed only when some candidate is too close to call).
+    double R = regDeg0;
+    double eps = 0.0;
+    bool fresh = true;                                       // R was computed from the current sums
     const bool tol_small = tol < 1.5;                        // accepted vectors then never shorten the sum
     const double turn = tol < 1.1 ? tol : 1.1;               // >= sin(tol) resp. the asin(1/L)*L bound
+    // lower bound of the norm of the angle-sum vector: every accepted unit vector lies within tol (< pi/2) of
+    // it, so it lengthens it by at least cos(tol)
+    const float cos_lb = tol_small ? cosf((float)tol) * 0.999f - 1e-6f : 0.0f;
+    float Llb = 0.999f;
     int n = 1;
     const int e = lane >> 3, k = lane & 7;
     const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
@@ -239,6 +260,10 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         int i = (sweep == 1 || !filter) ? 0 : n_start;       // contiguous cursor
         bool in_wl = (sweep > 1) && filter;
         while (true) {
+#ifdef LSD_PROFILE_GROW
+            long long tp = (long long)__builtin_amdgcn_s_memtime();
+            STAT(ST_ALLBATCHES, 1);
+#endif
             // ---- pick up to 8 entries ----
             int cnt, eidx;
             if (in_wl) {
@@ -264,39 +289,58 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     ensure_tiles(c, inb, nx, ny);
                 }
             }
+            PT(0);
             const int q = ny * w + nx;
-            const uint32_t word = inb ? c.t_st[cell] : 1u;
+            // all per-pixel reads of the batch are issued together (cell is in range even for !inb lanes)
+            const uint32_t word_r = c.t_st[cell];
+            const double d = c.t_deg[cell], sd = c.t_sn[cell], cd = c.t_cs[cell];
+            const uint32_t word = inb ? word_r : 1u;
             const bool cand = inb && (word >> 2) != id && (word & 3u) != 1u;       // :537 (2 is growable, Q5)
             const unsigned long long candm = __ballot(cand);
             unsigned long long acc = 0;                      // accepted lanes (one per accepted pixel)
             unsigned long long gone = 0;                     // every lane whose pixel became a member in this batch
+            PT(1);
             if (candm) {
-                const double d = cand ? c.t_deg[cell] : 0.0;
-                const double sd = cand ? c.t_sn[cell] : 0.0, cd = cand ? c.t_cs[cell] : 0.0;
-                // first occurrence (lowest lane) of every candidate pixel
-                if (cand) atomicMin(&c.claim[cell], (uint32_t)lane);
-                const bool winner = cand && c.claim[cell] == (uint32_t)lane;
-                if (cand) c.claim[cell] = 0xffffffffu;
-                // refresh the estimate once per batch
-                if (stale) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; stale = false; }
-                // margin: estimate error + worst-case drift while this batch's candidates are accepted
+                // first occurrence of every candidate pixel: a lane is a repeat iff an EARLIER entry of the batch
+                // has the pixel in its 3x3 neighbourhood (that entry's lane for it comes first in reference order)
+                bool winner = cand;
+                {
+                    const int ex0 = (int)(pk & 0xffffu), ey0 = (int)(pk >> 16);
+                    for (int e2 = 0; e2 + 1 < cnt; e2++) {
+                        const int px2 = __builtin_amdgcn_readlane(ex0, e2 * 8), py2 = __builtin_amdgcn_readlane(ey0, e2 * 8);
+                        if (e > e2 && abs(nx - px2) <= 1 && abs(ny - py2) <= 1) winner = false;
+                    }
+                }
+                // margin: error bound of R + worst-case drift while this batch's m candidates are accepted
                 const int m = __builtin_popcountll(__ballot(winner));
-                const float Lf = sqrtf((float)(sinS * sinS + cosS * cosS));
-                const double Ld = (double)Lf * 0.999 - (tol_small ? 0.0 : (double)m);
-                const double margin = Ld >= (tol_small ? 1.0 : 3.0) ? eps + 1.001 * (double)m * turn / Ld : 1e30;
-                const double raw = fabs(R - d);
-                const double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;  // :540-542
-                const bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
-                bool pc, amb;
-                if (margin == 0.0) { pc = dif < tol; amb = false; }               // :543 (exact R, nothing can drift)
-                else {
+                if (!tol_small) {                            // (rare: Refiner asked for a huge tolerance) no cheap norm bound
+                    if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
+                    const float sf = (float)sinS, cf = (float)cosS;
+                    Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
+                }
+                double margin = Llb >= (tol_small ? 0.9f : 3.0f)
+                                    ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7
+                                    : 1e30;
+                double raw = fabs(R - d);
+                double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;          // :540-542
+                bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
+                bool pc = !cut && dif < tol - margin;
+                bool amb = cut || (!pc && !(dif > tol + margin));
+                if (!fresh && tol_small && __ballot(cand && amb)) {
+                    // some candidate is too close to call with the drifted estimate: refresh it once and reclassify
+                    R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
+                    margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+                    raw = fabs(R - d);
+                    dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
+                    cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
                     pc = !cut && dif < tol - margin;
                     amb = cut || (!pc && !(dif > tol + margin));
                 }
                 const unsigned long long P = __ballot(winner && pc);              // accepted whatever the order
                 const unsigned long long A = __ballot(cand && amb);               // every occurrence, resolved in order
                 unsigned long long todo = P | A;
-                c.st_batches++;
+                STAT(ST_BATCHES, 1);
+                PT(2);
                 while (todo) {
                     const int l = __builtin_ctzll(todo);
                     todo &= todo - 1ull;
@@ -304,14 +348,15 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     if (!take) {
                         if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
                         const double dl = rl(d, l);
-                        if (stale) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; stale = false; }
+                        if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
                         double rw = fabs(R - dl);
                         double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
                         if (eps != 0.0 && (fabs(R) > kPi - eps || fabs(df - tol) <= eps || fabs(rw - kPi * 3 / 2.0) <= eps ||
                                            !(tol == tol))) {
                             R = atan2_g(sinS, cosS);         // :547, too close to call with the estimate
                             eps = 0.0;
-                            c.st_exact++;
+                            fresh = true;
+                            STAT(ST_EXACT, 1);
                             rw = fabs(R - dl);
                             df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
                         }
@@ -320,11 +365,15 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     if (take) {
                         cosS += rl(cd, l);                   // :545
                         sinS += rl(sd, l);                   // :546
-                        stale = true;
+                        // the estimate drifts by at most turn / |sum| per accepted pixel
+                        eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * (1.0f / Llb)) + 1e-9 : 1e30;
+                        Llb += cos_lb;
+                        fresh = false;
                         acc |= 1ull << l;
                         if (!((P >> l) & 1ull)) gone |= __ballot(cand && q == __builtin_amdgcn_readlane(q, l));
                     }
                 }
+                PT(3);
                 if (acc) {
                     const bool mine = (acc >> lane) & 1ull;
                     if (mine) {
@@ -335,9 +384,10 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     n += __builtin_popcountll(acc);
                     c.dirty = true;
                 }
+                PT(4);
                 // entries that still have a growable non-member neighbour go to the next sweep's worklist
-                if (filter) {
-                    const unsigned long long left = candm & ~gone & ~__ballot(cand && pc && margin != 1e30 && !amb);
+                const unsigned long long left = candm & ~gone & ~__ballot(cand && pc);
+                if (filter && left) {
                     const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
                     const unsigned long long hm = __ballot(has && k == 0);
                     const int add = __builtin_popcountll(hm);
@@ -348,6 +398,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     }
                 }
             }
+            PT(5);
             if (in_wl) wi += cnt; else i += cnt;
         }
         uint16_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
@@ -356,11 +407,11 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
     } while (n != ex);
     c.gnum = n;
     c.has_copy = false;
-    c.st_grow++;
-    c.st_grown += n;
-    if (n > LCAP) c.st_spill++;
-    if (n > c.st_maxreg) c.st_maxreg = n;
-    c.t_grow += (long long)__builtin_amdgcn_s_memtime() - t0;
+    STAT(ST_GROW, 1);
+    STAT(ST_GROWN, n);
+    if (n > LCAP) STAT(ST_SPILL, 1);
+    if (c.lane == 0 && (unsigned long long)n > c.stat[ST_MAXREG]) c.stat[ST_MAXREG] = (unsigned long long)n;
+    STAT(ST_TGROW, (long long)__builtin_amdgcn_s_memtime() - t0);
     out_num = n;
     out_sin = sinS;
     out_cos = cosS;
@@ -413,8 +464,10 @@ __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, do
     const double dI = Ixx - Iyy;
     const double lamb = (Ixx + Iyy - sqrt(dI * dI + 4 * Ixy * Ixy)) / 2.0;          // :647
     double inertiaDeg;
-    if (fabs(Ixx) > fabs(Iyy)) inertiaDeg = atan2_g(lamb - Ixx, Ixy);             // :649-652
-    else inertiaDeg = atan2_g(Ixy, lamb - Iyy);
+    {
+        const bool xx = fabs(Ixx) > fabs(Iyy);                                    // :649-652
+        inertiaDeg = atan2_g(xx ? lamb - Ixx : Ixy, xx ? Ixy : lamb - Iyy);
+    }
     double regDif = inertiaDeg - regdeg;                                          // :655-665
     while (regDif <= -kPi) regDif += 2 * kPi;
     while (regDif > kPi) regDif -= 2 * kPi;
@@ -447,7 +500,7 @@ __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, do
     r.cX = cenX; r.cY = cenY; r.deg = inertiaDeg; r.dx = dx; r.dy = dy;
     r.p = aliPro; r.prec = tol; r.pk = pk;
     if (r.wid < 1) r.wid = 1;                                                      // :730
-    c.t_rect += (long long)__builtin_amdgcn_s_memtime() - t0;
+    STAT(ST_TRECT, (long long)__builtin_amdgcn_s_memtime() - t0);
 }
 
 __device__ __forceinline__ double rec_density(int num, const Rec& r) {             // :757,:798,:827,:867
@@ -458,10 +511,10 @@ __device__ __forceinline__ double rec_density(int num, const Rec& r) {          
 // ---------------------------------------------------------------------------------------------
 // RegionRadiusReducer, myLSD.cpp:736-802 (incl. the `i <= num` sentinel behaviour)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
-                                           double denThre) {
+__device__ __forceinline__ bool radius_reduce_body(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
+                                                double denThre) {
     const int lane = c.lane, w = c.w;
-    c.st_rrr++;
+    STAT(ST_RRR, 1);
     double den = rec_density(num, rec);
     if (den > denThre) return true;                                                // :760
     // keep the grow-order list for the marking loops before it gets reordered
@@ -475,12 +528,12 @@ __device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num,
     bool removed_any = false;
     while (den < denThre) {                                                        // :775
         rad *= 0.75;
-        c.st_rrrpass++;
+        STAT(ST_RRRPASS, 1);
         int i = 0;
         while (i <= num) {                                                         // :779 (`<=`)
             int px, py;
             if (i == num) {
-                if (!removed_any) { c.st_oob++; break; }   // the reference reads out of bounds here (UB): no removal
+                if (!removed_any) { STAT(ST_OOB, 1); break; }   // the reference reads out of bounds here (UB): no removal
                 px = 0; py = 0;                            // slot holds the NULL written at :784-785
             } else {
                 const uint32_t pkx = lget(c, i);
@@ -494,7 +547,7 @@ __device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num,
                     if (i == num) { lset(c, num - 1, 0u); }
                     else { lset(c, i, lget(c, num - 1)); lset(c, num - 1, 0u); }   // :782-785
                 }
-                if (i == num) c.st_sent++;
+                if (i == num) STAT(ST_SENT, 1);
                 wg_fence();
                 removed_any = true;
                 i--;
@@ -507,6 +560,21 @@ __device__ __forceinline__ bool radius_reduce(RCtx& c, int sx, int sy, int& num,
         den = rec_density(num, rec);
     }
     return true;
+}
+
+// Cold path (a handful of calls per image): kept out of line, with the context passed BY VALUE so that the
+// caller's context stays in registers.  *copied_out tells the caller that lst was reordered (gcopy holds the
+// grow-order list).
+__device__ __noinline__ bool radius_reduce(RCtx c, int sx, int sy, int* num_io, double regdeg, Rec* rec_io,
+                                           double denThre, int* copied_out) {
+    int num = *num_io;
+    Rec rec = *rec_io;
+    c.has_copy = false;
+    const bool ok = radius_reduce_body(c, sx, sy, num, regdeg, rec, denThre);
+    *num_io = num;
+    *rec_io = rec;
+    *copied_out = c.has_copy ? 1 : 0;
+    return ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,7 +593,7 @@ __device__ double log_gamma_dev(const RCtx& c, int x) {
 __device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
     const int lane = c.lane, xLim = c.w, yLim = c.h;
     const double logNT = c.logNT;
-    c.st_nfa++;
+    STAT(ST_NFA, 1);
     double verX[4], verY[4];
     verX[0] = rec.x1 - rec.dy * rec.wid / 2.0;                                     // :949-956
     verX[1] = rec.x2 - rec.dy * rec.wid / 2.0;
@@ -579,7 +647,7 @@ __device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
         c.s_incl[lane] = inc; c.s_lo[lane] = lo; c.s_x[lane] = xr;
         wg_fence();
         all += tot;
-        c.st_nfapx += tot;
+        STAT(ST_NFAPX, tot);
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
             bool hit = false;
@@ -626,7 +694,7 @@ __device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
 __device__ __forceinline__ double rect_nfa(RCtx& c, const Rec& rec) {
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     const double v = rect_nfa_impl(c, rec);
-    c.t_nfa += (long long)__builtin_amdgcn_s_memtime() - t0;
+    STAT(ST_TNFA, (long long)__builtin_amdgcn_s_memtime() - t0);
     return v;
 }
 
@@ -669,12 +737,11 @@ __device__ __forceinline__ double improve(RCtx& c, Rec& rec_io) {
     return bestNFA;
 }
 
-// Refiner, myLSD.cpp:804-880
-__device__ __forceinline__ bool refine(RCtx& c, int sx, int sy, int& num, double& regdeg, Rec& rec, double denThre) {
+// Refiner, myLSD.cpp:804-880, first half: the re-estimated angle tolerance (:833-855).  The regrow (:857),
+// the refit (:866) and the density checks are in the caller's two-pass loop so that grow() and
+// rect_convert() are inlined once.
+__device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, const Rec& rec, double cenDeg) {
     const int lane = c.lane, w = c.w;
-    double den = rec_density(num, rec);
-    if (den >= denThre) return true;                                               // :829
-    const double cenDeg = c.deg[(size_t)sy * w + sx];
     double difSum = 0, squSum = 0;
     int ptNum = 0;
     for (int base = 0; base < num; base += 64) {                                   // :839-853
@@ -703,15 +770,7 @@ __device__ __forceinline__ bool refine(RCtx& c, int sx, int sy, int& num, double
         }
     }
     const double meanDif = difSum / (ptNum * 1.0);
-    const double tol2 = 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
-    double gs, gc;
-    grow(c, sx, sy, cenDeg, tol2, num, gs, gc);                                    // :857
-    if (num < 2) return false;                                                     // :861
-    regdeg = atan2_g(gs, gc);                                                      // reg.deg (:547, :581)
-    rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec, rec);                    // :866
-    den = rec_density(num, rec);
-    if (den < denThre) return radius_reduce(c, sx, sy, num, regdeg, rec, denThre); // :869-877
-    return true;
+    return 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -738,7 +797,7 @@ __device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, int& bx0, int
         x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
     }
     bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
-    c.t_mark += (long long)__builtin_amdgcn_s_memtime() - t0;
+    STAT(ST_TMARK, (long long)__builtin_amdgcn_s_memtime() - t0);
 }
 
 // bounding box of the pixels currently in the region list
@@ -778,14 +837,14 @@ struct Ring {
     int numo[RW];        // (final_num << 2) | outcome
 };
 
-__global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t id_base) {
+__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
     __shared__ uint32_t lst[NW][LCAP];
     __shared__ uint16_t wl0[NW][LCAP], wl1[NW][LCAP];
     __shared__ double t_deg[NW][NSLOT * 64], t_sn[NW][NSLOT * 64], t_cs[NW][NSLOT * 64];
     __shared__ uint32_t t_st[NW][NSLOT * 64];
-    __shared__ uint32_t claim[NW][NSLOT * 64];
     __shared__ int t_tag[NW][NSLOT];
     __shared__ int s_incl[NW][64], s_lo[NW][64], s_x[NW][64];
+    __shared__ unsigned long long s_stat[NW][ST_COUNT];
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
@@ -803,16 +862,13 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
     c.lst = lst[wave]; c.wl0 = wl0[wave]; c.wl1 = wl1[wave];
     c.t_st = t_st[wave]; c.t_deg = t_deg[wave]; c.t_sn = t_sn[wave]; c.t_cs = t_cs[wave]; c.t_tag = t_tag[wave];
-    c.claim = claim[wave]; c.s_incl = s_incl[wave]; c.s_lo = s_lo[wave]; c.s_x = s_x[wave];
+    c.s_incl = s_incl[wave]; c.s_lo = s_lo[wave]; c.s_x = s_x[wave];
     c.tilesX = (w + 7) >> 3; c.dirty = false;
     c.cur_id = id_base; c.gnum = 0; c.has_copy = false;
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
-    c.st_grow = c.st_grown = c.st_nfa = c.st_rrr = c.st_rrrpass = c.st_sent = c.st_oob = c.st_spill = 0;
-    c.t_grow = c.t_rect = c.t_nfa = c.t_mark = c.st_maxreg = c.st_nfapx = 0;
-    c.st_exact = c.st_tilefetch = c.st_batches = c.t_tiles = c.t_chain = c.t_commit = 0;
-    long long st_redo = 0, st_discard = 0, t_wait = 0;
+    c.stat = s_stat[wave];
+    if (lane < ST_COUNT) c.stat[lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
-    for (int j = lane; j < NSLOT * 64; j += 64) c.claim[j] = 0xffffffffu;
     if (lane < NSLOT) c.t_tag[lane] = -1;
     for (int j = threadIdx.x; j < RW; j += 64 * NW) rg.state[j] = R_EMPTY;
 
@@ -946,17 +1002,31 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
         Rec rec;
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         if (!skip) {
-            double regdeg, gs, gc;
+            // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
+            // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
+            // re-estimated by Refiner (:833-857).  grow() and rect_convert() are thereby inlined once.
             const double seedDeg = c.deg[pp];
-            grow(c, sx, sy, seedDeg, g.degThre, num, gs, gc);                         // :225
-            num0 = num;
-            bool done = num < g.regThre;                                              // :228 (not marked, Q5)
-            if (!done) {
+            double tol = g.degThre, regdeg = seedDeg, gs, gc;
+            bool done = false;
+            for (int pass = 0; pass < 2 && !done; pass++) {
+                grow(c, sx, sy, seedDeg, tol, num, gs, gc);                           // :225 / :857
+                if (pass == 0) {
+                    num0 = num;
+                    if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
+                } else if (num < 2) { outcome = 1; done = true; break; }              // :861
                 regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                         // reg.deg (:547, :581)
-                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232
-                if (spec && rec_density(num, rec) < g.denThre) list_bbox(c, num, fx0, fy0, fx1, fy1);   // refine() will regrow
-                const bool ok = refine(c, sx, sy, num, regdeg, rec, g.denThre);       // :234
-                if (!ok) { outcome = 1; done = true; }                                // :237
+                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232 / :866 (p, prec still the defaults)
+                const double den = rec_density(num, rec);
+                if (pass == 0) {
+                    if (den >= g.denThre) break;                                      // :829 dense enough
+                    if (spec) list_bbox(c, num, fx0, fy0, fx1, fy1);                  // the regrow replaces this list
+                    tol = refine_tol(c, sx, sy, num, rec, seedDeg);                   // :833-855
+                } else if (den < g.denThre) {                                         // :869-877
+                    int copied = 0;
+                    const bool ok = radius_reduce(c, sx, sy, &num, regdeg, &rec, g.denThre, &copied);
+                    c.has_copy = copied != 0;                // lst was reordered: gcopy holds the grow-order list
+                    if (!ok) { outcome = 1; done = true; }
+                }
             }
             if (!done) {
                 logNFA = improve(c, rec);                                             // :240
@@ -1006,22 +1076,22 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
                 if (lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) { abandon = true; break; }   // somebody has to redo f: me
                 __builtin_amdgcn_s_sleep(4);
             }
-            t_wait += (long long)__builtin_amdgcn_s_memtime() - tw0;
+            STAT(ST_WAIT, (long long)__builtin_amdgcn_s_memtime() - tw0);
             if (abandon) {                                 // give up this result; it is re-evaluated when the cursor gets here
                 if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
-                st_redo++;
+                STAT(ST_REDO, 1);
                 continue;
             }
             wg_fence();
             bool bad = (c.state[pp] & 3u) != 0u;           // an earlier seed marked the pixel meanwhile
             if (bad) {
-                st_discard++;
+                STAT(ST_DISCARD, 1);
                 if (lane == 0) { lds_st(&s_commit, k + 1); }
                 continue;
             }
             const int now = lds_ld(&s_epoch);
             if (now != epoch_snap && hit_since(epoch_snap, now, x0, y0, x1, y1)) {
-                st_redo++;
+                STAT(ST_REDO, 1);
                 forced_k = k;                              // evaluate again; everything earlier is committed now
                 continue;
             }
@@ -1067,20 +1137,13 @@ __global__ __launch_bounds__(64 * NW) void k_region(Geom g, Buffers b, uint32_t 
         b.counts[img] = s_lines;
         if (b.nseed) b.nseed[img] = s_ntrace;
     }
-    if (lane == 0 && b.stats) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 24);
-        atomicAdd(&st[0], (unsigned long long)c.st_grow); atomicAdd(&st[1], (unsigned long long)c.st_grown);
-        atomicAdd(&st[2], (unsigned long long)c.st_nfa); atomicAdd(&st[3], (unsigned long long)c.st_rrr);
-        atomicAdd(&st[4], (unsigned long long)c.st_rrrpass); atomicAdd(&st[5], (unsigned long long)c.st_sent);
-        atomicAdd(&st[6], (unsigned long long)c.st_oob); atomicAdd(&st[7], (unsigned long long)c.st_spill);
-        if (wave == 0) { st[8] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); st[15] = (unsigned long long)nseeds; }
-        atomicAdd(&st[9], (unsigned long long)c.t_grow); atomicAdd(&st[10], (unsigned long long)c.t_rect);
-        atomicAdd(&st[11], (unsigned long long)c.t_nfa); atomicAdd(&st[12], (unsigned long long)c.t_mark);
-        atomicMax(&st[13], (unsigned long long)c.st_maxreg); atomicAdd(&st[14], (unsigned long long)c.st_nfapx);
-        atomicAdd(&st[16], (unsigned long long)c.st_exact); atomicAdd(&st[17], (unsigned long long)c.st_tilefetch);
-        atomicAdd(&st[18], (unsigned long long)c.st_batches); atomicAdd(&st[19], (unsigned long long)c.t_tiles);
-        atomicAdd(&st[20], (unsigned long long)st_redo); atomicAdd(&st[21], (unsigned long long)st_discard);
-        atomicAdd(&st[22], (unsigned long long)t_wait);
+    if (b.stats) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 32);
+        if (lane == 0 && wave == 0) { c.stat[ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); c.stat[ST_SEEDS] = (unsigned long long)nseeds; }
+        if (lane < ST_COUNT) {
+            if (lane == ST_MAXREG) atomicMax(&st[lane], c.stat[lane]);
+            else atomicAdd(&st[lane], c.stat[lane]);
+        }
     }
 }
 

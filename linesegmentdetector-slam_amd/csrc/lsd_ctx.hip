@@ -179,7 +179,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, hipMemset(c->stamps, 0, tot * nwv * sizeof(uint32_t)));
         c->run_id = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * 24));
+        HIPCHK(c, re_alloc(&c->stats, nn * 32));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp;
@@ -327,7 +327,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_n * c->cap_npx * (size_t)region_waves() * sizeof(uint32_t), s));
             c->run_id = 1;
         }
-        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 24 * n, s));
+        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
         launch_region(g, b, n, c->run_id << 20, s);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -466,7 +466,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * 24; need = 192; break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * 32; need = 256; break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

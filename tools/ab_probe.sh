@@ -1,0 +1,6 @@
+#!/bin/bash
+# developer probe: compares alternative builds of the library (paths relative to the repo root)
+for lib in "$@"; do
+  echo "== $lib"
+  LSD_HIP_LIB=$PWD/$lib python tools/scale_probe.py 2048 1 512 2>&1 | grep -E "^(1|512) " | cut -c1-200
+done

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Developer probe: per-image region-stage cycles for the whole bench batch; prints the distribution and the slowest images."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, torch
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+maps = bench.load_maps()
+n, size = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 2048
+ctx = lsd.Context(0)
+d = torch.from_numpy(bench.make_batch(maps, n, size)).cuda()
+lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+for rep in range(2):
+    ctx.enqueue_device(d.data_ptr(), n, size, size, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
+print({k: round(v, 2) for k, v in ctx.timings().items()})
+wh = lsd.scaled_size(size, size)
+st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
+tot = np.array([x["cycles_total"] for x in st]) / 1e6
+print("Mcycles total: mean %.0f median %.0f p90 %.0f max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
+for i in np.argsort(-tot)[:6]:
+    x = st[i]
+    print(i, "src", bench.SOURCES[i % 4], "flip", (i // 4) % 4, {k: (v // 1000000 if k.startswith(("cycles", "pt_")) else v) for k, v in x.items() if not k.startswith("_")})
