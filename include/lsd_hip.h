@@ -134,6 +134,10 @@ int lsd_debug_fetch(lsd_ctx *ctx, int image, int what, void *out, size_t bytes);
  * doubles: fn 0 = sin/cos(a) -> out0,out1; fn 1 = atan2(a, b) -> out0; fn 2 = atan(a) -> out0. */
 int lsd_debug_eval_math(lsd_ctx *ctx, int fn, const double *a, const double *b, double *out0, double *out1, size_t n);
 
+/* Profiling hook: streams `bytes` once with 8-B-per-lane stores (k_calib_write8) and once with 8-B-per-lane loads
+ * (k_calib_read8) so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE can be calibrated for the front end's access shape. */
+int lsd_debug_calibrate(lsd_ctx *ctx, size_t bytes);
+
 /* Per-kernel device time (ms) of the last lsd_run/lsd_run_batch, measured with HIP events on the
  * context's stream: [0] gauss, [1] gradient, [2] sort, [3] region, [4] lines, [5] total. */
 int lsd_last_timings(lsd_ctx *ctx, float ms_out[6]);

@@ -14,6 +14,26 @@ __global__ void k_dbgmath(int fn, const double* __restrict__ a, const double* __
     else { o0[i] = atan_g(a[i]); o1[i] = 0; }
 }
 
+// PMC calibration (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE are only calibrated for 16-B-per-lane
+// streams, while the LSD front end moves 8 B (fp64) and 1 B (u8) per lane.  These two kernels stream a known
+// number of bytes with exactly those access shapes so that rocprofv3 --pmc readings can be scaled.
+__global__ void k_calib_read8(const double* __restrict__ a, double* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0;
+    for (; i < n; i += stride) acc += a[i];
+    if (acc == 123.456) out[0] = acc;
+}
+__global__ void k_calib_write8(double* __restrict__ a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = (double)i;
+}
+void launch_calib(double* buf, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_calib_write8, dim3(8192), dim3(256), 0, s, buf, n);
+    hipLaunchKernelGGL(k_calib_read8, dim3(8192), dim3(256), 0, s, buf, buf, n);
+}
+
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_dbgmath, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, a, b, o0, o1, n);
 }

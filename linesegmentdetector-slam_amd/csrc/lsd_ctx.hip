@@ -474,6 +474,17 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
     return LSD_OK;
 }
 
+int lsd_debug_calibrate(lsd_ctx* c, size_t bytes) {
+    if (!c || bytes < 8) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    double* buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, bytes));
+    launch_calib(buf, bytes / 8, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(buf);
+    return LSD_OK;
+}
+
 int lsd_debug_eval_math(lsd_ctx* c, int fn, const double* a, const double* b, double* out0, double* out1, size_t n) {
     if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 2 || (fn == 1 && !b)) return LSD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));

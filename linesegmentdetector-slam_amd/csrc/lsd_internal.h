@@ -74,6 +74,7 @@ void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
 int region_waves();
+void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 
