@@ -418,6 +418,198 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
 }
 
 // ---------------------------------------------------------------------------------------------
+// grow8(): RegionGrower for EIGHT seeds at once, one seed per group of 8 lanes (lane = group*8 + neighbour).
+//
+// The serial chain of RegionGrower keeps one wavefront busy with a single frontier pixel per step in the
+// common case (thin structures grow one pixel at a time), which leaves 56 of 64 lanes idle.  Here every group
+// runs the same state machine on its own region -- one frontier entry per step, its 8 neighbours on the
+// group's 8 lanes -- so one instruction stream advances eight regions.  Per-group state lives in registers
+// (identical in the 8 lanes of a group); the region list, the sweep worklists and the curMap stamps of a group
+// are private arrays in HBM, the last 64 list entries are mirrored in an LDS ring (the frontier is at the tail).
+// Semantics per group are exactly those of grow(): reference order of the tests (entry by entry, neighbours
+// row-major), sums accumulated in that order, estimate + rigorous margin with exact fallback, worklist sweeps.
+// ---------------------------------------------------------------------------------------------
+constexpr int NG = 8;
+
+struct G8 {                      // per-lane results (identical within a group)
+    int n;                       // region size; -1: list capacity exceeded (caller falls back to grow())
+    double sinS, cosS;
+    int bx0, by0, bx1, by1;      // bounding box of the region
+};
+
+__device__ __forceinline__ unsigned grp_bits(unsigned long long m, int g) { return (unsigned)((m >> (8 * g)) & 0xffull); }
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
+
+__device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_t* glist, uint32_t* gwl, uint16_t* gstamp,
+                                      uint16_t id, uint32_t* ring, int gcap, double tol, G8& out) {
+    const int lane = c.lane, w = c.w, h = c.h;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    const int g = lane >> 3, j = lane & 7, gbase = g * 8;
+    const int kk = j + (j >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
+    const int ox = kk % 3 - 1, oy = kk / 3 - 1;
+    uint32_t* rg8 = ring + g * 64;
+    uint32_t* wl_cur = gwl;
+    uint32_t* wl_nxt = gwl + gcap;
+
+    // seed (:512-520)
+    double sinS = 0, cosS = 1, R = 0;
+    if (act) {
+        const size_t q0 = (size_t)sy * w + sx;
+        R = c.deg[q0]; sinS = c.sn[q0]; cosS = c.cs[q0];     // regDeg, sin/cos(regDeg) (:515-516)
+        if (j == 0) {
+            __hip_atomic_store(&gstamp[q0], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            glist[0] = pack_xy(sx, sy); rg8[0] = pack_xy(sx, sy);
+        }
+    }
+    double eps = 0.0;
+    bool fresh = true;
+    const bool tol_small = tol < 1.5;
+    const double turn = tol < 1.1 ? tol : 1.1;
+    const float cos_lb = tol_small ? cosf((float)tol) * 0.999f - 1e-6f : 0.0f;
+    float Llb = 0.999f;
+    int n = 1, i = 0, ex = 1, wi = 0, wl_cnt = 0, nxt_cnt = 0;
+    bool in_wl = false, filter = true, done = !act, overflow = false;
+    wg_fence();
+
+    while (__ballot(!done)) {
+        // ---- pick this group's next entry (one per step) ----
+        bool have = false;
+        int eidx = 0;
+        if (!done) {
+            if (in_wl) {
+                if (wi < wl_cnt) { eidx = (int)wl_cur[wi]; have = true; }
+                else in_wl = false;
+            }
+            if (!have && !in_wl) {
+                if (i < n) { eidx = i; have = true; }        // n is live (:529)
+                else {                                       // sweep finished (:525)
+                    uint32_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
+                    wl_cnt = nxt_cnt; nxt_cnt = 0; wi = 0;
+                    if (n == ex) done = true;
+                    else { ex = n; in_wl = filter; i = filter ? n : 0; }
+                }
+            }
+        }
+        uint32_t pk = 0;
+        if (have) pk = (n - eidx <= 64) ? rg8[eidx & 63] : glist[eidx];
+        const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+        const bool inb = have && nx >= 0 && ny >= 0 && nx < w && ny < h;                  // :536
+        const size_t q = (size_t)(inb ? ny : 0) * w + (inb ? nx : 0);
+        uint32_t uw = 1u; uint16_t st = 0;
+        double d = 0, sd = 0, cd = 0;
+        if (inb) {
+            uw = c.state[q];
+            // the group's own 16-bit stamps are re-read right after being stored: go to L2 (sc1), not through the CU's L1
+            st = __hip_atomic_load(&gstamp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d = c.deg[q]; sd = c.sn[q]; cd = c.cs[q];
+        }
+        const bool cand = inb && st != id && (uw & 3u) != 1u;                             // :537 (2 is growable, Q5)
+        const unsigned cb = grp_bits(__ballot(cand), g);
+        const int m = __builtin_popcount(cb);
+        if (!tol_small && cb) {                              // (rare) no cheap norm bound: refresh every step
+            if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
+            const float sf = (float)sinS, cf = (float)cosS;
+            Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
+        }
+        double margin = Llb >= (tol_small ? 0.9f : 3.0f) ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+        double raw = fabs(R - d);
+        double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;                   // :540-542
+        bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
+        bool pc = !cut && dif < tol - margin;
+        bool amb = cut || (!pc && !(dif > tol + margin));
+        unsigned ab = grp_bits(__ballot(cand && amb), g);
+        if (!fresh && tol_small && ab) {                     // too close to call with the drifted estimate: refresh once
+            R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
+            margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+            raw = fabs(R - d);
+            dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
+            cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
+            pc = !cut && dif < tol - margin;
+            amb = cut || (!pc && !(dif > tol + margin));
+        }
+        const unsigned long long pm = __ballot(cand && pc), am = __ballot(cand && amb);
+        const unsigned pb = grp_bits(pm, g);
+        ab = grp_bits(am, g);
+        unsigned accb = 0;
+        // ---- the chain: neighbour jj of every group takes its turn (reference order inside a group) ----
+        #pragma unroll 1
+        for (int jj = 0; jj < 8; jj++) {
+            const unsigned bit = 1u << jj;
+            const bool isp = (pb & bit) != 0u, isa = (ab & bit) != 0u;
+            if (!__ballot(isp || isa)) continue;
+            bool take = isp;
+            if (isa) {
+                const double dl = shfl_d(d, gbase + jj);
+                if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
+                double rw = fabs(R - dl);
+                double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                if (eps != 0.0 && (fabs(R) > kPi - eps || fabs(df - tol) <= eps || fabs(rw - kPi * 3 / 2.0) <= eps || !(tol == tol))) {
+                    R = atan2_g(sinS, cosS);                 // :547, too close to call with the estimate
+                    eps = 0.0; fresh = true;
+                    STAT(ST_EXACT, 1);
+                    rw = fabs(R - dl);
+                    df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                }
+                take = df < tol;                             // :543
+            }
+            const double cdl = shfl_d(cd, gbase + jj), sdl = shfl_d(sd, gbase + jj);
+            if (take) {
+                cosS += cdl;                                 // :545
+                sinS += sdl;                                 // :546
+                eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * (1.0f / Llb)) + 1e-9 : 1e30;
+                Llb += cos_lb;
+                fresh = false;
+                accb |= bit;
+            }
+        }
+        // ---- commit the accepted neighbours (:549-556) ----
+        if (accb) {
+            const int na = __builtin_popcount(accb);
+            if (n + na > gcap) { overflow = true; done = true; }
+            else {
+                if (accb & (1u << j)) {
+                    const int idx = n + __builtin_popcount(accb & ((1u << j) - 1u));
+                    const uint32_t pv = pack_xy(nx, ny);
+                    __hip_atomic_store(&gstamp[q], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    glist[idx] = pv;
+                    rg8[idx & 63] = pv;
+                }
+                n += na;
+            }
+        }
+        // entries that still have a growable non-member neighbour go to the next sweep's worklist
+        if (have && filter && (cb & ~(pb | accb))) {
+            if (nxt_cnt >= gcap) filter = false;
+            else { if (j == 0) wl_nxt[nxt_cnt] = (uint32_t)eidx; nxt_cnt++; }
+        }
+        if (have) { if (in_wl) wi++; else i++; }
+        wg_fence();                                          // this step's stamps / list / worklist stores precede the next step's loads
+    }
+    // bounding boxes (for the speculation check), 8 lanes per region
+    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+    if (act && !overflow) {
+        for (int e2 = j; e2 < n; e2 += 8) {
+            const uint32_t pv = (n - e2 <= 64) ? rg8[e2 & 63] : glist[e2];
+            const int x = (int)(pv & 0xffffu), y = (int)(pv >> 16);
+            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+        }
+    }
+    for (int off = 4; off >= 1; off >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
+        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
+    }
+    if (act && j == 0) {
+        atomicAdd(&c.stat[ST_GROW], 1ull);
+        atomicAdd(&c.stat[ST_GROWN], (unsigned long long)n);
+        atomicMax(&c.stat[ST_MAXREG], (unsigned long long)n);
+    }
+    out.n = overflow ? -1 : n;
+    out.sinS = sinS; out.cosS = cosS;
+    out.bx0 = x0; out.by0 = y0; out.bx1 = x1; out.by1 = y1;
+    STAT(ST_TGROW, (long long)__builtin_amdgcn_s_memtime() - t0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // CenterGetter (:592-619) + OrientationGetter (:621-667) + RectangleConverter (:669-734)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
@@ -777,7 +969,7 @@ __device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, c
 // seed loop, myLSD.cpp:219-272
 // ---------------------------------------------------------------------------------------------
 // usedMap marking (:243-248 / :259-265) restricted to the grown pixels; returns their bounding box.
-__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, int& bx0, int& by0, int& bx1, int& by1) {
+__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, bool all_listed, int& bx0, int& by0, int& bx1, int& by1) {
     const int w = c.w;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     wg_fence();                                   // the stamps written by grow() must have landed
@@ -787,7 +979,7 @@ __device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, int& bx0, int
         const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         const size_t q = (size_t)y * w + x;
-        if (c.stamp[q] == c.cur_id) {             // curMap == 1 only
+        if (all_listed || c.stamp[q] == c.cur_id) {   // curMap == 1 only (a group-mode region is exactly its list)
             c.state[q] = val;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
@@ -837,7 +1029,7 @@ struct Ring {
     int numo[RW];        // (final_num << 2) | outcome
 };
 
-__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
+__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base, uint32_t id_base16) {
     __shared__ uint32_t lst[NW][LCAP];
     __shared__ uint16_t wl0[NW][LCAP], wl1[NW][LCAP];
     __shared__ double t_deg[NW][NSLOT * 64], t_sn[NW][NSLOT * 64], t_cs[NW][NSLOT * 64];
@@ -845,6 +1037,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     __shared__ int t_tag[NW][NSLOT];
     __shared__ int s_incl[NW][64], s_lo[NW][64], s_x[NW][64];
     __shared__ unsigned long long s_stat[NW][ST_COUNT];
+    __shared__ uint32_t g_ring[NW][NG * 64];             // tails of the 8 group-mode region lists of a wave
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
@@ -940,6 +1133,28 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
                     break;
                 }
+#ifdef LSD_VERIFY_GROW8
+                if (now != snap) {                         // not flagged as a conflict: verify by growing again at the cursor
+                    const uint32_t ppv = ord[seedidx[f]];
+                    if ((c.state[ppv] & 3u) == 0u && (rg.numo[f & (RW - 1)] & 3) == 0) {
+                        const int vx = (int)(ppv % (uint32_t)w), vy = (int)(ppv / (uint32_t)w);
+                        int vn; double vs, vc;
+                        wg_fence(); invalidate_tiles(c);
+                        grow(c, vx, vy, c.deg[ppv], g.degThre, vn, vs, vc);
+                        if (vn != rg.num0[f & (RW - 1)]) {
+                            STAT(ST_R23, 1);
+                            if (lane == 0 && c.stat[ST_R31] == 0ull) {
+                                c.stat[ST_R31] = ((unsigned long long)(unsigned)f << 32) | ((unsigned)rg.num0[f & (RW - 1)] << 16) | (unsigned)vn;
+                                c.stat[ST_PT0] = ((unsigned long long)(unsigned)snap << 32) | (unsigned)now;
+                                c.stat[ST_PT1] = ((unsigned long long)(unsigned short)bx[0] << 48) | ((unsigned long long)(unsigned short)bx[1] << 32) | ((unsigned long long)(unsigned short)bx[2] << 16) | (unsigned long long)(unsigned short)bx[3];
+                                const short* r0 = s_ring[snap & (RING - 1)];
+                                c.stat[ST_PT2] = ((unsigned long long)(unsigned short)r0[0] << 48) | ((unsigned long long)(unsigned short)r0[1] << 32) | ((unsigned long long)(unsigned short)r0[2] << 16) | (unsigned long long)(unsigned short)r0[3];
+                                c.stat[ST_PT3] = ((unsigned long long)(unsigned)vx << 32) | (unsigned)vy;
+                            }
+                        }
+                    }
+                }
+#endif
                 bool used_now = false;
                 if (trace) used_now = (c.state[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
                 if (!used_now) {
@@ -954,12 +1169,24 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (lane == 0) lds_st(&s_lock, 0);
     };
 
+    // group-mode storage of this wave's 8 groups (lane -> group lane>>3)
+    const int grp = lane >> 3;
+    uint32_t* my_glist = b.glist + ((img * NW + wave) * NG + grp) * (size_t)b.gcap;
+    uint32_t* my_gwl = b.gwl + ((img * NW + wave) * NG + grp) * 2 * (size_t)b.gcap;
+    uint16_t* my_gstamp = b.gstamp + ((img * NW + wave) * NG + grp) * npx;
+    uint32_t gid_local = 0;                                // grows of this group in this run (16-bit stamp = id_base16 + it)
+
     int forced_k = -1;                                     // seed to (re)evaluate non-speculatively at the cursor
+    int blk_k0 = 0, blk_g = NG, blk_snap = 0;              // current block of 8 consecutive seeds, next group to hand over
+    G8 blk;                                                // per-lane results of the block (group = lane>>3)
+    blk.n = 0; blk.sinS = 0; blk.cosS = 0; blk.bx0 = blk.by0 = 0; blk.bx1 = blk.by1 = -1;
+    bool blk_skip = true;
     while (true) {
         // ---- choose the next job ----
         int k;
-        bool spec;
-        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; }
+        bool spec, from_group = false;
+        int epoch_snap;
+        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; epoch_snap = lds_ld(&s_epoch); }
         else {
             // a record waiting to be redone at the cursor has priority
             const int f = lds_ld(&s_commit);
@@ -968,24 +1195,77 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 if (lane == 0) won = atomicCAS(&rg.state[f & (RW - 1)], R_REDO, R_BUSY) == R_REDO ? 1 : 0;
                 won = __builtin_amdgcn_readfirstlane(won);
             }
-            if (won) { k = f; spec = false; }
-            else {
+            if (won) { k = f; spec = false; epoch_snap = lds_ld(&s_epoch); }
+            else if (blk_g < NG) {
+                // ---- hand over the next result of the current block ----
+                const int gq = blk_g++;
+                k = blk_k0 + gq;
+                if (k >= nseeds) { blk_g = NG; continue; }
+                const int src = gq * 8;
+                const bool gskip = __builtin_amdgcn_readlane((int)blk_skip, src) != 0;
+                const int gn = __builtin_amdgcn_readlane(blk.n, src);
+                if (gskip) {
+                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
+                    if (gq == NG - 1) advance();
+                    continue;
+                }
+                if (gn >= 0 && gn < g.regThre) {           // small region (:228): nothing to evaluate, nothing to mark
+                    // cross-lane reads stay in uniform control flow (values of inactive lanes are not defined inside a branch)
+                    const int qx0 = __builtin_amdgcn_readlane(blk.bx0, src), qy0 = __builtin_amdgcn_readlane(blk.by0, src);
+                    const int qx1 = __builtin_amdgcn_readlane(blk.bx1, src), qy1 = __builtin_amdgcn_readlane(blk.by1, src);
+                    if (lane == 0) {
+                        const int r = k & (RW - 1);
+                        rg.snap[r] = blk_snap;
+                        rg.box[r][0] = (short)(qx0 - 1);
+                        rg.box[r][1] = (short)(qy0 - 1);
+                        rg.box[r][2] = (short)(qx1 + 1);
+                        rg.box[r][3] = (short)(qy1 + 1);
+                        rg.num0[r] = gn; rg.numo[r] = (gn << 2) | 0;
+                        lds_st(&rg.state[r], R_LIGHT);
+                    }
+                    if (gq == NG - 1) advance();
+                    continue;
+                }
+                spec = true;
+                epoch_snap = blk_snap;
+                from_group = gn >= 0;                      // gn < 0: list overflow in group mode -> plain grow() below
+            } else {
                 if (lds_ld(&s_next) >= nseeds) {           // nothing left to hand out: help until everything is committed
                     advance();
                     if (lds_ld(&s_commit) >= nseeds) break;
                     __builtin_amdgcn_s_sleep(8);
                     continue;
                 }
-                if (lds_ld(&s_next) - f >= RW - NW) {      // run-ahead window full
+                if (lds_ld(&s_next) - f >= RW - NW * NG) { // run-ahead window full
                     advance();
                     __builtin_amdgcn_s_sleep(8);
                     continue;
                 }
-                k = 0;
-                if (lane == 0) k = atomicAdd(&s_next, 1);
-                k = __builtin_amdgcn_readfirstlane(k);
-                if (k >= nseeds) continue;
-                spec = true;
+                // ---- fetch a block of 8 consecutive seeds and grow them together ----
+                int k0 = 0;
+                if (lane == 0) k0 = atomicAdd(&s_next, NG);
+                k0 = __builtin_amdgcn_readfirstlane(k0);
+                if (k0 >= nseeds) continue;
+                blk_k0 = k0; blk_g = 0;
+                blk_snap = lds_ld(&s_epoch);               // before anything of usedMap is read for these seeds
+                wg_fence();
+                const int kg = k0 + grp;
+                bool gact = kg < nseeds;
+                int gsx = 0, gsy = 0;
+                if (gact) {
+                    const uint32_t ppg = ord[seedidx[kg]];
+                    gsx = (int)(ppg % (uint32_t)w); gsy = (int)(ppg / (uint32_t)w);
+                    if ((c.state[ppg] & 3u) != 0u) gact = false;          // monotone: once used, always used (:222)
+                }
+                blk_skip = !gact;
+                if (gid_local >= 2047u) {                  // 16-bit stamp range of this run exhausted: plain grow() for the rest
+                    blk.n = -1;
+                } else {
+                    gid_local++;
+                    grow8(c, gact, gsx, gsy, my_glist, my_gwl, my_gstamp, (uint16_t)(id_base16 + gid_local), g_ring[wave],
+                          b.gcap, g.degThre, blk);
+                }
+                continue;
             }
         }
         const int oidx = (int)seedidx[k];
@@ -993,23 +1273,37 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
         // ---- evaluate ----
-        const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
-        wg_fence();
+        if (!from_group) { wg_fence(); }
         invalidate_tiles(c);
-        const bool skip = (c.state[pp] & 3u) != 0u;       // monotone: once used, always used (:222)
+        const bool skip = from_group ? false : (c.state[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int outcome = 0, num = 0, num0 = 0;
         double logNFA = 0;
         Rec rec;
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
+        bool cur_is_group = false;                         // curMap == the group-mode list (no stamps of this wave)
         if (!skip) {
             // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
-            // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
-            // re-estimated by Refiner (:833-857).  grow() and rect_convert() are thereby inlined once.
+            // global tolerance (or takes the region grown in group mode), pass 1 (only when the rectangle is too
+            // sparse, :829) regrows with the tolerance re-estimated by Refiner (:833-857).
             const double seedDeg = c.deg[pp];
             double tol = g.degThre, regdeg = seedDeg, gs, gc;
             bool done = false;
             for (int pass = 0; pass < 2 && !done; pass++) {
-                grow(c, sx, sy, seedDeg, tol, num, gs, gc);                           // :225 / :857
+                if (pass == 0 && from_group) {
+                    // the region of seed k was grown by group (k - blk_k0): bring its list into this wave's list storage
+                    const int src = (k - blk_k0) * 8;
+                    num = __builtin_amdgcn_readlane(blk.n, src);
+                    gs = rl(blk.sinS, src); gc = rl(blk.cosS, src);
+                    const uint32_t* gl = b.glist + ((img * NW + wave) * NG + (k - blk_k0)) * (size_t)b.gcap;
+                    for (int k2 = lane; k2 < num && k2 < LCAP; k2 += 64) c.lst[k2] = gl[k2];
+                    for (int k2 = LCAP + lane; k2 < num; k2 += 64) c.spill[k2 - LCAP] = gl[k2];
+                    c.gnum = num; c.has_copy = false;
+                    cur_is_group = true;
+                    wg_fence();
+                } else {
+                    grow(c, sx, sy, seedDeg, tol, num, gs, gc);                       // :225 / :857
+                    cur_is_group = false;
+                }
                 if (pass == 0) {
                     num0 = num;
                     if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
@@ -1102,7 +1396,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             int bx0, by0, bx1, by1;
             if (outcome == 2) {                                                      // :242-250
-                mark_region(c, 2u, bx0, by0, bx1, by1);
+                mark_region(c, 2u, cur_is_group, bx0, by0, bx1, by1);
             } else if (outcome == 3) {
                 const int li = s_lines;
                 if (li < b.max_lines && lane == 0) {
@@ -1117,7 +1411,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     double* rs = recs_scaled + (size_t)li * 4;
                     rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
                 }
-                mark_region(c, 1u, bx0, by0, bx1, by1);                              // :259-265
+                mark_region(c, 1u, cur_is_group, bx0, by0, bx1, by1);                              // :259-265
                 wg_fence();                               // the marks must be visible before the epoch moves
                 if (lane == 0) {
                     const int ep = s_epoch;
@@ -1147,9 +1441,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     }
 }
 
-void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
-    hipLaunchKernelGGL(k_region, dim3(n), dim3(64 * NW), 0, s, g, b, id_base);
+void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
+    hipLaunchKernelGGL(k_region, dim3(n), dim3(64 * NW), 0, s, g, b, id_base, id_base16);
 }
+
+int region_groups() { return NW * NG; }
 
 int region_waves() { return NW; }
 

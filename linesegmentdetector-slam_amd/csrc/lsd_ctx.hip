@@ -31,6 +31,10 @@ struct lsd_ctx {
            *recs_scaled = nullptr;
     uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
     uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number
+    uint32_t run16 = 0;    // same for the 16-bit group stamps: (run16 << 11) + grow number, run16 in [1, 31]
+    uint32_t *glist = nullptr, *gwl = nullptr;
+    uint16_t* gstamp = nullptr;
+    int gcap = 16384;
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
@@ -178,6 +182,11 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, re_alloc(&c->stamps, tot * nwv)); HIPCHK(c, re_alloc(&c->seedidx, tot));
         HIPCHK(c, hipMemset(c->stamps, 0, tot * nwv * sizeof(uint32_t)));
         c->run_id = 0;
+        const size_t ngr = (size_t)region_groups();
+        HIPCHK(c, re_alloc(&c->glist, nn * ngr * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, nn * ngr * 2 * (size_t)c->gcap));
+        HIPCHK(c, re_alloc(&c->gstamp, tot * ngr));
+        HIPCHK(c, hipMemset(c->gstamp, 0, tot * ngr * sizeof(uint16_t)));
+        c->run16 = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * 32));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
@@ -251,7 +260,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -303,6 +312,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.stamps = c->stamps; b.seedidx = c->seedidx;
+    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
@@ -328,7 +338,11 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             c->run_id = 1;
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
-        launch_region(g, b, n, c->run_id << 20, s);
+        if (++c->run16 >= 32u) {
+            HIPCHK(c, hipMemsetAsync(c->gstamp, 0, c->cap_n * c->cap_npx * (size_t)region_groups() * sizeof(uint16_t), s));
+            c->run16 = 1;
+        }
+        launch_region(g, b, n, c->run_id << 20, c->run16 << 11, s);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     if (c->stop_after == 0) launch_lines(g, b, n, s);

@@ -46,6 +46,11 @@ struct Buffers {
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
+    // group-mode region growing (8 seeds per wavefront): per (image, wave, group) private storage
+    uint32_t* glist;       // n x NW*8 x gcap : region list (grow order)
+    uint32_t* gwl;         // n x NW*8 x 2 x gcap : sweep worklists
+    uint16_t* gstamp;      // n x NW*8 x npx : curMap stamps (16-bit generations)
+    int gcap;
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
     int32_t* counts;       // n
@@ -72,7 +77,8 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
-void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
+void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
+int region_groups();   // seed groups per image (NW * 8)
 int region_waves();
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
