@@ -430,6 +430,8 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
 // row-major), sums accumulated in that order, estimate + rigorous margin with exact fallback, worklist sweeps.
 // ---------------------------------------------------------------------------------------------
 constexpr int NG = 8;
+constexpr int G8_MIN_STEPS = 24;    // group mode always runs this many steps ...
+constexpr int G8_MIN_ACTIVE = 3;    // ... and goes on while at least this many of the 8 regions are still growing
 
 struct G8 {                      // per-lane results (identical within a group)
     int n;                       // region size; -1: list capacity exceeded (caller falls back to grow())
@@ -471,7 +473,16 @@ __device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_
     bool in_wl = false, filter = true, done = !act, overflow = false;
     wg_fence();
 
-    while (__ballot(!done)) {
+    int steps = 0;
+    while (true) {
+        const unsigned long long live = __ballot(!done);
+        if (!live) break;
+        // Eight regions share every step; once most of them are finished the few long ones are cheaper in the
+        // batched wave-wide grow() (8 frontier pixels per step for ONE region): hand them over (n = -1).
+        if (++steps > G8_MIN_STEPS && __builtin_popcountll(live) < 8 * G8_MIN_ACTIVE) {
+            if (!done) { overflow = true; done = true; }
+            break;
+        }
         // ---- pick this group's next entry (one per step) ----
         bool have = false;
         int eidx = 0;
@@ -625,6 +636,10 @@ __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, do
         const double wgt = valid ? c.mag[(size_t)y * w + x] : 0.0;
         const double ax = wgt * x, ay = wgt * y;
         const int cnt = min(64, num - base);
+        if (cnt == 64) {                         // full chunk: constant lane indices (no scalar loop overhead)
+            #pragma unroll
+            for (int j = 0; j < 64; j++) { cenX += rl(ax, j); cenY += rl(ay, j); ws += rl(wgt, j); }
+        } else
         for (int j = 0; j < cnt; j++) {          // serial accumulation in list order (bit-exact)
             cenX += rl(ax, j);
             cenY += rl(ay, j);
@@ -645,6 +660,10 @@ __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, do
         const double ddy = y - cenY, ddx = x - cenX;
         const double a = wgt * (ddy * ddy), b = wgt * (ddx * ddx), cc = wgt * ddx * ddy;
         const int cnt = min(64, num - base);
+        if (cnt == 64) {
+            #pragma unroll
+            for (int j = 0; j < 64; j++) { Ixx += rl(a, j); Iyy += rl(b, j); Ixy -= rl(cc, j); ws += rl(wgt, j); }
+        } else
         for (int j = 0; j < cnt; j++) {
             Ixx += rl(a, j);
             Iyy += rl(b, j);

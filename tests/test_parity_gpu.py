@@ -298,6 +298,21 @@ def test_full_size_batch_properties(maps, lsdmod, ctx, oracle):
         assert np.all(L["len"] > 0) and np.all(np.abs(np.hypot(L["x2"] - L["x1"], L["y2"] - L["y1"]) - L["len"]) < 1e-9)
 
 
+def test_bench_batch_sample_matches_oracle(maps, lsdmod, ctx, oracle):
+    """A 32-image slice of the bench batch (2048x2048, all four sources, all flips, the heaviest 'mapValue' tiles included)
+    run as ONE batch -- every wavefront of the region stage speculating at once -- against the oracle image by image."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ids = list(range(16)) + [27, 151, 155, 183, 187, 203, 244, 271, 347, 355, 383, 391, 419, 496, 51, 55]
+    batch = np.stack([bench.make_image(maps, i, 2048) for i in ids])
+    lines, offs, ims = ctx.run_batch(batch.copy())
+    for j, i in enumerate(ids):
+        ref = oracle.lsd(batch[j].copy())
+        assert offs[j + 1] - offs[j] == len(ref["lines"]), i
+        assert_lines_close(lines[offs[j]:offs[j + 1]], ref["lines"])
+        assert np.array_equal(ims[j], ref["lineIm"]), i
+
+
 def test_cpp_adapter_runs(maps, tmp_path):
     """The C++ host side (include/myLSD.h) end to end: same line count as the recorded reference answer."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
