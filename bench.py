@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--max-lines", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lineim", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
     a = ap.parse_args()
 
     import torch
@@ -102,7 +103,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or (a.force_dist and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)    # RCCL
 
@@ -128,7 +130,7 @@ def main():
     def step(collect):
         ctx.enqueue_device(d_maps.data_ptr(), n, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(),
                            d_line_ims=None if d_ims is None else d_ims.data_ptr(), stream=stream)
-        if world > 1:
+        if use_dist:
             res = ldist.gather_line_lists(d_lines, d_counts, n_total, dst=0)
         else:
             res = None
@@ -138,7 +140,7 @@ def main():
         return res
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +156,7 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     nl = d_counts.sum().to(torch.float64).reshape(1)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nl, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -162,7 +164,7 @@ def main():
     overflow = int((d_counts > a.max_lines).sum().item())
 
     if rank == 0:
-        if world > 1:
+        if use_dist:
             offsets, lines = res
             assert int(offsets[-1]) == int(total_lines) and lines.shape[0] == int(total_lines)
         ms_per_step = dt / a.steps * 1e3
@@ -195,7 +197,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(maps, size, first)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
