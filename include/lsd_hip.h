@@ -101,6 +101,19 @@ int lsd_reserve(lsd_ctx *ctx, int n, int cols, int rows);
 /* Blocks until the stream used by the last enqueue is idle. */
 int lsd_synchronize(lsd_ctx *ctx);
 
+/* --- createMapCache (SURVEY 8f "next" #1) ------------------------------------------------------ */
+/* Replaces mylsd::createMapCache(Mat MapGray, double res) (LSD/myLSD.h:131, LSD/myLSD.cpp:11-127): distance (metres)
+ * from every cell to the occupied cell (value 1) whose breadth-first flood reaches it first, capped at
+ * z_occ_max_dis (LSD/baseFunc.h:60; unreachable cells hold z_occ_max_dis, occupied cells 0).
+ *   map  rows x cols uint8 (pitch `stride`), read-only -- call it BEFORE lsd_run, which rewrites the map (Q2);
+ *   out  rows x cols doubles, packed (the CV_64FC1 mapCache FeatureAssociation reads, LSD/myFA.cpp:371-380).
+ * Bit-identical to the reference (integer flood order + one exactly rounded sqrt and multiply per cell). */
+int lsd_map_cache(lsd_ctx *ctx, const uint8_t *map, int cols, int rows, size_t stride, double res,
+                  double z_occ_max_dis, double *out);
+/* The same for n packed device-resident maps (d_out: n x rows x cols doubles), asynchronous on `stream`. */
+int lsd_enqueue_map_cache_device(lsd_ctx *ctx, const uint8_t *d_maps, int n, int cols, int rows, double res,
+                                 double z_occ_max_dis, double *d_out, void *stream);
+
 /* --- introspection used by the parity tests and the bench ------------------------------- */
 /* Scaled size of a cols x rows map: w = floor(cols*sca), h = floor(rows*sca) (myLSD.cpp:132-133). */
 void lsd_scaled_size(int cols, int rows, double sca, int *w, int *h);

@@ -128,6 +128,24 @@ inline structLSD myLineSegmentDetector(Mat MapGray, int oriMapCol, int oriMapRow
     return r;
 }
 
+/* mylsd::createMapCache (LSD/myLSD.h:131, LSD/myLSD.cpp:11-127): CV_64FC1 rows x cols, metres, capped at
+ * z_occ_max_dis (LSD/baseFunc.h:60).  Must run before myLineSegmentDetector (which rewrites MapGray). */
+#ifdef LSD_WITH_OPENCV
+typedef cv::Mat MatF64;
+inline MatF64 make_f64(int rows, int cols) { return cv::Mat::zeros(rows, cols, CV_64FC1); }
+#else
+typedef lsd::Image<double> MatF64;
+inline MatF64 make_f64(int rows, int cols) { return MatF64::zeros(rows, cols); }
+#endif
+inline MatF64 createMapCache(Mat MapGray, double res, double z_occ_max_dis_ = 1.0) {
+    lsd_ctx* c = context();
+    MatF64 out = make_f64(MapGray.rows, MapGray.cols);
+    const int st = lsd_map_cache(c, MapGray.template ptr<unsigned char>(0), MapGray.cols, MapGray.rows, (size_t)MapGray.step,
+                                 res, z_occ_max_dis_, out.template ptr<double>(0));
+    if (st != LSD_OK) throw lsd_error(st, std::string(lsd_strerror(st)) + ": " + lsd_last_error(c));
+    return out;
+}
+
 /* north_star's name for the same call, with the LSD/baseFunc.h:64-68 defaults */
 inline structLSD runLSD(Mat MapGray, double sca = 0.3, double sig = 0.6, double angThre = 22.5,
                         double denThre = 0.7, int pseBin_ = 1024) {

@@ -26,6 +26,7 @@ STAGE_ALL, STAGE_GAUSS, STAGE_GRAD, STAGE_SORT, STAGE_REGION = range(5)
 
 # LSD defaults, LSD/baseFunc.h:64-68
 lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin = 0.3, 0.6, 22.5, 0.7, 1024
+z_occ_max_dis = 1.0   # LSD/baseFunc.h:60
 
 
 class lsd_params(C.Structure):
@@ -91,6 +92,9 @@ def load_library(path=None):
     L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
     L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    L.lsd_map_cache.restype = i; L.lsd_map_cache.argtypes = [vp, vp, i, i, sz, dbl, dbl, vp]
+    L.lsd_enqueue_map_cache_device.restype = i
+    L.lsd_enqueue_map_cache_device.argtypes = [vp, vp, i, i, i, dbl, dbl, vp, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -101,7 +105,8 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
                     "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
-                    "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate"]
+                    "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
+                    "lsd_enqueue_map_cache_device"]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -184,6 +189,19 @@ class Context:
         p = params or make_params()
         return self._chk(self.L.lsd_enqueue_batch_device(self.h, d_maps, n, cols, rows, C.byref(p), flags, d_line_ims,
                                                          d_lines, max_lines, d_counts, stream))
+
+    def map_cache(self, map_u8, res, z_occ_max_dis=1.0):
+        """lsd_map_cache on a uint8 image (read-only); returns float64 [rows, cols]."""
+        assert map_u8.dtype == np.uint8 and map_u8.ndim == 2
+        rows, cols = map_u8.shape
+        out = np.zeros((rows, cols), np.float64)
+        self._chk(self.L.lsd_map_cache(self.h, map_u8.ctypes.data, cols, rows, map_u8.strides[0], float(res),
+                                       float(z_occ_max_dis), out.ctypes.data))
+        return out
+
+    def enqueue_map_cache_device(self, d_maps, n, cols, rows, res, z_occ_max_dis, d_out, stream=None):
+        return self._chk(self.L.lsd_enqueue_map_cache_device(self.h, d_maps, n, cols, rows, float(res),
+                                                             float(z_occ_max_dis), d_out, stream))
 
     def reserve(self, n, cols, rows):
         self._chk(self.L.lsd_reserve(self.h, n, cols, rows))
@@ -283,6 +301,12 @@ def myLineSegmentDetector(MapGray, oriMapCol, oriMapRow, sca, sig, angThre, denT
     ctx = ctx or default_context()
     lines, line_im = ctx.run(MapGray, make_params(sca, sig, angThre, denThre, pseBin))
     return structLSD(line_im, lines)
+
+
+def createMapCache(MapGray, res, ctx=None):
+    """mylsd::createMapCache (LSD/myLSD.h:131, LSD/myLSD.cpp:11): CV_64FC1-like float64 array, metres, capped at
+    z_occ_max_dis.  Call it before myLineSegmentDetector, which rewrites MapGray."""
+    return (ctx or default_context()).map_cache(MapGray, res, z_occ_max_dis)
 
 
 def runLSD(MapGray, oriMapCol=None, oriMapRow=None, sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre,

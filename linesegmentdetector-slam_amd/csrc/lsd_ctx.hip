@@ -52,6 +52,12 @@ struct lsd_ctx {
     lsd_params tab_params{};
     bool tab_valid = false;
     int tapR = 0;
+    // createMapCache workspace
+    unsigned long long* mc_claim = nullptr;
+    uint32_t *mc_fa = nullptr, *mc_fb = nullptr;
+    uint8_t* mc_in = nullptr;
+    double* mc_out = nullptr;
+    size_t mc_cap = 0, mc_hcap = 0;
     // options
     int stop_after = 0;
     bool trace = false;
@@ -262,7 +268,7 @@ void lsd_destroy(lsd_ctx* c) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
-                    c->d_taps, c->d_lgamma, c->d_ptab};
+                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -485,6 +491,43 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
     }
     if (bytes < need) return LSD_ERR_INVALID;
     if (need) HIPCHK(c, hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    return LSD_OK;
+}
+
+int lsd_enqueue_map_cache_device(lsd_ctx* c, const uint8_t* d_maps, int n, int cols, int rows, double res,
+                                 double z_occ_max_dis, double* d_out, void* stream) {
+    if (!c || !d_maps || !d_out || n <= 0 || cols <= 0 || rows <= 0 || !(res > 0) || !(z_occ_max_dis >= 0)) return LSD_ERR_INVALID;
+    if ((long long)cols * rows >= (1ll << 31)) return LSD_ERR_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t need = (size_t)n * cols * rows;
+    if (need > c->mc_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->mc_claim, need)); HIPCHK(c, re_alloc(&c->mc_fa, need * 2)); HIPCHK(c, re_alloc(&c->mc_fb, need * 2));
+        c->mc_cap = need;
+    }
+    const int cell_radius = cvt_x86(floor(z_occ_max_dis / res));           // myLSD.cpp:13
+    launch_mapcache(d_maps, d_out, c->mc_claim, c->mc_fa, c->mc_fb, n, cols, rows, res, z_occ_max_dis, cell_radius, s);
+    HIPCHK(c, hipGetLastError());
+    c->last_stream = s;
+    return LSD_OK;
+}
+
+int lsd_map_cache(lsd_ctx* c, const uint8_t* map, int cols, int rows, size_t stride, double res, double z_occ_max_dis,
+                  double* out) {
+    if (!c || !map || !out || cols <= 0 || rows <= 0 || stride < (size_t)cols) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t wh = (size_t)cols * rows;
+    if (wh > c->mc_hcap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->mc_in, wh)); HIPCHK(c, re_alloc(&c->mc_out, wh));
+        c->mc_hcap = wh;
+    }
+    HIPCHK(c, hipMemcpy2DAsync(c->mc_in, cols, map, stride, cols, rows, hipMemcpyHostToDevice, c->stream));
+    const int st = lsd_enqueue_map_cache_device(c, c->mc_in, 1, cols, rows, res, z_occ_max_dis, c->mc_out, c->stream);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(out, c->mc_out, wh * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LSD_OK;
 }
 

@@ -81,6 +81,8 @@ void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uin
 int region_groups();   // seed groups per image (NW * 8)
 int region_waves();
 void launch_calib(double* buf, size_t n, hipStream_t s);
+void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
+                     int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 

@@ -338,3 +338,50 @@ def test_cpp_adapter_runs(maps, tmp_path):
     n, nl, lit, x1, _ = p.stdout.split()
     assert int(n) == 480 * 608 and int(nl) == 7 and int(lit) == 545
     assert abs(float(x1) - 351.00301936775691) < ENDPOINT_TOL
+
+
+# ---- createMapCache: integer flood order + exactly rounded sqrt -> BIT-EXACT --------------
+@pytest.mark.parametrize("name", FIXTURES)
+def test_map_cache_fixture_parity(name, maps, maps_meta, known, lsdmod, ctx, oracle):
+    img = maps[name]
+    res = maps_meta[name]["res"]
+    got = ctx.map_cache(img, res)
+    ref = oracle.map_cache(img.copy(), res)
+    assert np.array_equal(got, ref)
+    csum, ccnt = known["counts"][name][2:]
+    assert abs(float(got.sum()) - csum) < 1e-5 and int((got < 1.0).sum()) == ccnt   # the reference's recorded answers
+
+
+def test_map_cache_tile2048_and_reference_name(maps, known, lsdmod, ctx, oracle):
+    img = tile2048(maps["aisle1"])
+    got = lsdmod.createMapCache(img, 0.025, ctx=ctx)
+    assert np.array_equal(got, oracle.map_cache(img.copy(), 0.025))
+    csum, ccnt = known["counts"]["tile2048"][2:]
+    assert abs(float(got.sum()) - csum) < 1e-4 and int((got < 1.0).sum()) == ccnt
+
+
+@pytest.mark.parametrize("seed,rows,cols,res", [(1, 97, 131, 0.05), (2, 300, 40, 0.025), (3, 64, 64, 0.2), (4, 5, 700, 0.1)])
+def test_map_cache_synthetic(seed, rows, cols, res, lsdmod, ctx, oracle):
+    rng = np.random.default_rng(seed)
+    m = np.zeros((rows, cols), np.uint8)
+    m[rng.random((rows, cols)) < 0.02] = 1
+    m[rng.random((rows, cols)) < 0.3] = 255
+    m[0, 0] = 1; m[rows - 1, cols - 1] = 1                                   # sources on the borders
+    assert np.array_equal(ctx.map_cache(m, res), oracle.map_cache(m.copy(), res))
+    empty = np.zeros((rows, cols), np.uint8)                                 # no occupied cell at all
+    assert np.array_equal(ctx.map_cache(empty, res), np.full((rows, cols), 1.0))
+    full = np.ones((rows, cols), np.uint8)                                   # every cell occupied
+    assert not ctx.map_cache(full, res).any()
+
+
+def test_map_cache_device_batch(maps, lsdmod, ctx, oracle):
+    import torch
+    src = maps["aisle2"][:512, :1024]
+    batch = np.stack([src, src[::-1].copy(), np.roll(src, 100, 1)]).copy()
+    d = torch.from_numpy(batch).cuda()
+    out = torch.zeros(batch.shape, dtype=torch.float64, device="cuda")
+    ctx.enqueue_map_cache_device(d.data_ptr(), 3, 1024, 512, 0.025, 1.0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert np.array_equal(out[i].cpu().numpy(), oracle.map_cache(batch[i].copy(), 0.025))
+    assert np.array_equal(d.cpu().numpy(), batch)
