@@ -38,7 +38,11 @@ namespace lsdhip {
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
 constexpr int NSLOT = 4;     // tile-cache slots per wave (2 x 2 tiles)
-constexpr int RING = 64;     // remembered bounding boxes of recently accepted lines
+constexpr int RING = 128;    // remembered bounding boxes of recently accepted lines
+#ifndef LSD_REGION_NB
+#define LSD_REGION_NB 1
+#endif
+constexpr int NB = LSD_REGION_NB;        // blocks of 8 seeds a wave may have in flight (evaluated, waiting for their turn to commit)
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
@@ -53,6 +57,8 @@ struct RCtx {
     uint32_t* stamp;     // this wave's curMap stamps
     uint32_t* spill;
     uint32_t* gcopy;
+    float2* meta;        // HBM [mcap]: (angle estimate, slack) of the last full test of a list entry, see grow()
+    int mcap;
     const double* sn;
     const double* cs;
     uint32_t* lst;       // LDS [LCAP]
@@ -251,6 +257,13 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
     uint16_t* wl_nxt = c.wl1;
     int wl_cnt = 0;                                          // entries of wl_cur (sweep >= 2)
     bool filter = true;                                      // false once the list outgrew the worklists
+    // Re-sweeps: an entry whose remaining candidates all failed by more than the region angle has moved since cannot
+    // accept anything now either (membership and bans only grow); it is carried over to the next worklist without
+    // touching its neighbourhood.  meta[entry] = (angle estimate its candidates were compared with, smallest
+    // "distance - tol" among the candidates left), checked 64 entries at a time.
+    unsigned long long flt_need = 0;                         // chunk [flt_base, flt_base + 64) of wl_cur: entries to test in full
+    int flt_base = 0;
+    bool flt_valid = false;
     int sweep = 1, ex;
     do {                                                     // :525 sweeps to fixpoint (Q7)
         ex = n;
@@ -269,6 +282,42 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
             if (in_wl) {
                 if (wi >= wl_cnt) { in_wl = false; continue; }
                 cnt = min(8, wl_cnt - wi);
+                if (tol_small && filter) {
+                    if (!flt_valid || wi >= flt_base + 64) {
+                        if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
+                        flt_base = wi;
+                        bool nd = false;
+                        if (wi + lane < wl_cnt) {
+                            const int ei = (int)wl_cur[wi + lane];
+                            nd = true;
+                            if (ei < c.mcap) {
+                                const float2 mt = c.meta[ei];
+                                float dr = fabsf((float)R - mt.x);
+                                if (dr > 3.14159265f) dr = 6.28318531f - dr;
+                                nd = !(dr + (float)eps + 1e-5f < mt.y);
+                            }
+                        }
+                        flt_need = __ballot(nd);
+                        flt_valid = true;
+                    }
+                    const int off = wi - flt_base;
+                    const int nval = min(64, wl_cnt - flt_base) - off;         // entries of the chunk from wi on
+                    const unsigned long long rest = flt_need >> off;          // bit 0 = entry wi
+                    const int nskip = rest ? min(__builtin_ctzll(rest), nval) : nval;
+                    if (nskip > 0) {                         // a run of entries that cannot accept anything: carry them over
+                        if (nxt_cnt + nskip > LCAP) filter = false;
+                        else {
+                            if (lane < nskip) wl_nxt[nxt_cnt + lane] = wl_cur[wi + lane];
+                            nxt_cnt += nskip;
+                        }
+                        wi += nskip;
+                        STAT(ST_R31, nskip);
+                        continue;
+                    }
+                    // the run of consecutive entries to test (no skipped entry in between: its check would be stale after an accept)
+                    const unsigned long long inv = ~rest;
+                    cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
+                }
                 eidx = e < cnt ? (int)wl_cur[wi + e] : 0;
             } else {
                 if (i >= n) break;                           // n is live (:529)
@@ -336,10 +385,12 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     pc = !cut && dif < tol - margin;
                     amb = cut || (!pc && !(dif > tol + margin));
                 }
+                const double Rcls = R;                       // the angle dif was taken against
                 const unsigned long long P = __ballot(winner && pc);              // accepted whatever the order
                 const unsigned long long A = __ballot(cand && amb);               // every occurrence, resolved in order
                 unsigned long long todo = P | A;
                 STAT(ST_BATCHES, 1);
+                if (sweep > 1) STAT(ST_R23, 1);
                 PT(2);
                 while (todo) {
                     const int l = __builtin_ctzll(todo);
@@ -383,12 +434,22 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     }
                     n += __builtin_popcountll(acc);
                     c.dirty = true;
+                    flt_valid = false;                       // the region angle moved
                 }
                 PT(4);
                 // entries that still have a growable non-member neighbour go to the next sweep's worklist
                 const unsigned long long left = candm & ~gone & ~__ballot(cand && pc);
                 if (filter && left) {
                     const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
+                    if (tol_small) {                         // slack of this entry's remaining candidates (circular distance - tol)
+                        float mg = 3.0e38f;
+                        if ((left >> lane) & 1ull) {
+                            const double rw = fabs(Rcls - d);
+                            mg = (float)((rw > kPi ? 2.0 * kPi - rw : rw) - tol);
+                        }
+                        mg = fminf(mg, __shfl_xor(mg, 1)); mg = fminf(mg, __shfl_xor(mg, 2)); mg = fminf(mg, __shfl_xor(mg, 4));
+                        if (has && k == 0 && eidx < c.mcap) c.meta[eidx] = make_float2((float)Rcls, mg - 4e-6f);
+                    }
                     const unsigned long long hm = __ballot(has && k == 0);
                     const int add = __builtin_popcountll(hm);
                     if (nxt_cnt + add > LCAP || n > 65535) filter = false;
@@ -404,6 +465,8 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         uint16_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
         wl_cnt = nxt_cnt;
         sweep++;
+        flt_valid = false;
+        wg_fence();                                          // meta[] written in this sweep is read in the next
     } while (n != ex);
     c.gnum = n;
     c.has_copy = false;
@@ -988,17 +1051,19 @@ __device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, c
 // seed loop, myLSD.cpp:219-272
 // ---------------------------------------------------------------------------------------------
 // usedMap marking (:243-248 / :259-265) restricted to the grown pixels; returns their bounding box.
-__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, bool all_listed, int& bx0, int& by0, int& bx1, int& by1) {
+__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, const uint32_t* src, int src_cnt, int& bx0, int& by0, int& bx1,
+                                            int& by1) {
     const int w = c.w;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     wg_fence();                                   // the stamps written by grow() must have landed
     c.dirty = false;
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-    for (int k2 = c.lane; k2 < c.gnum; k2 += 64) {
-        const uint32_t pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
+    const int cnt = src ? src_cnt : c.gnum;
+    for (int k2 = c.lane; k2 < cnt; k2 += 64) {
+        const uint32_t pkx = src ? src[k2] : (c.has_copy ? c.gcopy[k2] : lget(c, k2));
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         const size_t q = (size_t)y * w + x;
-        if (all_listed || c.stamp[q] == c.cur_id) {   // curMap == 1 only (a group-mode region is exactly its list)
+        if (src || c.stamp[q] == c.cur_id) {      // curMap == 1 only (src: a stashed list holds exactly those)
             c.state[q] = val;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
@@ -1059,6 +1124,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     __shared__ uint32_t g_ring[NW][NG * 64];             // tails of the 8 group-mode region lists of a wave
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
+    __shared__ int s_q[NW][2][NB];                       // in-flight blocks of a wave: first seed, accept epoch at fetch
     __shared__ Ring rg;
 
     const size_t img = blockIdx.x;
@@ -1072,6 +1138,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     c.sn = b.sn + img * npx; c.cs = b.cs + img * npx;
     c.stamp = b.stamps + (img * NW + wave) * npx;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
+    c.meta = reinterpret_cast<float2*>(b.wmeta) + (img * NW + wave) * (size_t)b.mcap; c.mcap = b.mcap;
     c.lst = lst[wave]; c.wl0 = wl0[wave]; c.wl1 = wl1[wave];
     c.t_st = t_st[wave]; c.t_deg = t_deg[wave]; c.t_sn = t_sn[wave]; c.t_cs = t_cs[wave]; c.t_tag = t_tag[wave];
     c.s_incl = s_incl[wave]; c.s_lo = s_lo[wave]; c.s_x = s_x[wave];
@@ -1161,8 +1228,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         wg_fence(); invalidate_tiles(c);
                         grow(c, vx, vy, c.deg[ppv], g.degThre, vn, vs, vc);
                         if (vn != rg.num0[f & (RW - 1)]) {
-                            STAT(ST_R23, 1);
-                            if (lane == 0 && c.stat[ST_R31] == 0ull) {
+                                            if (lane == 0 && c.stat[ST_R31] == 0ull) {
                                 c.stat[ST_R31] = ((unsigned long long)(unsigned)f << 32) | ((unsigned)rg.num0[f & (RW - 1)] << 16) | (unsigned)vn;
                                 c.stat[ST_PT0] = ((unsigned long long)(unsigned)snap << 32) | (unsigned)now;
                                 c.stat[ST_PT1] = ((unsigned long long)(unsigned short)bx[0] << 48) | ((unsigned long long)(unsigned short)bx[1] << 32) | ((unsigned long long)(unsigned short)bx[2] << 16) | (unsigned long long)(unsigned short)bx[3];
@@ -1190,7 +1256,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 
     // group-mode storage of this wave's 8 groups (lane -> group lane>>3)
     const int grp = lane >> 3;
-    uint32_t* my_glist = b.glist + ((img * NW + wave) * NG + grp) * (size_t)b.gcap;
+    uint32_t* const wave_glist = b.glist + (img * NW + wave) * (size_t)NB * NG * b.gcap;   // [NB][NG][gcap]
     uint32_t* my_gwl = b.gwl + ((img * NW + wave) * NG + grp) * 2 * (size_t)b.gcap;
     uint16_t* my_gstamp = b.gstamp + ((img * NW + wave) * NG + grp) * npx;
     uint32_t gid_local = 0;                                // grows of this group in this run (16-bit stamp = id_base16 + it)
@@ -1200,11 +1266,33 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     G8 blk;                                                // per-lane results of the block (group = lane>>3)
     blk.n = 0; blk.sinS = 0; blk.cosS = 0; blk.bx0 = blk.by0 = 0; blk.bx1 = blk.by1 = -1;
     bool blk_skip = true;
+    // Results that mark usedMap ("heavy") are stashed -- record in pend[], pixel list in the seed's glist slot of the
+    // block's buffer -- and the wave carries on: with the rest of its block, then with up to NB - 1 further blocks.
+    // Stashed results are committed in seed order as the cursor reaches them (the oldest block of the wave first).
+    int q_head = 0, q_cnt = 0, cur_buf = 0;                // ring of NB block buffers: oldest, blocks in flight, newest
+    unsigned pend32 = 0;                                   // byte i = slots of buffer i holding a stashed result
+    int* const qk = s_q[wave][0];
+    int* const qs = s_q[wave][1];
+    double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NB * NG * 24;
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    long long tl = (long long)__builtin_amdgcn_s_memtime();
+#define LT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT(ST_PT0 + (i), t_ - tl); tl = t_; } while (0)
     while (true) {
         // ---- choose the next job ----
         int k;
-        bool spec, from_group = false;
+        bool spec, from_group = false, from_stash = false;
         int epoch_snap;
+        int st_buf = 0, st_k0 = 0;                         // buffer / first seed of the block a stashed result belongs to
+        LT(5);
+        // retire blocks whose results are all handed over and committed
+        while (q_cnt > 0 && ((pend32 >> (8 * q_head)) & 0xffu) == 0u && (q_cnt > 1 || blk_g >= NG)) {
+            q_head = (q_head + 1) % NB; q_cnt--;
+        }
+        int kp = -1;                                       // earliest stashed result of this wave
+        if (q_cnt > 0) {
+            const unsigned m = (pend32 >> (8 * q_head)) & 0xffu;
+            if (m) { st_buf = q_head; st_k0 = qk[q_head]; kp = st_k0 + __builtin_ctz(m); }
+        }
         if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; epoch_snap = lds_ld(&s_epoch); }
         else {
             // a record waiting to be redone at the cursor has priority
@@ -1215,7 +1303,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 won = __builtin_amdgcn_readfirstlane(won);
             }
             if (won) { k = f; spec = false; epoch_snap = lds_ld(&s_epoch); }
-            else if (blk_g < NG) {
+            else if (kp == f) {
+                // ---- the cursor is at a stashed result of this wave: commit it ----
+                k = kp;
+                from_stash = true; spec = true; epoch_snap = qs[st_buf];
+            }
+            else if (q_cnt > 0 && blk_g < NG) {
                 // ---- hand over the next result of the current block ----
                 const int gq = blk_g++;
                 k = blk_k0 + gq;
@@ -1248,25 +1341,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 spec = true;
                 epoch_snap = blk_snap;
                 from_group = gn >= 0;                      // gn < 0: list overflow in group mode -> plain grow() below
-            } else {
-                if (lds_ld(&s_next) >= nseeds) {           // nothing left to hand out: help until everything is committed
-                    advance();
-                    if (lds_ld(&s_commit) >= nseeds) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    continue;
-                }
-                if (lds_ld(&s_next) - f >= RW - NW * NG) { // run-ahead window full
-                    advance();
-                    __builtin_amdgcn_s_sleep(8);
-                    continue;
-                }
+            } else if (q_cnt < NB && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - NW * NG) {
                 // ---- fetch a block of 8 consecutive seeds and grow them together ----
                 int k0 = 0;
                 if (lane == 0) k0 = atomicAdd(&s_next, NG);
                 k0 = __builtin_amdgcn_readfirstlane(k0);
                 if (k0 >= nseeds) continue;
+                cur_buf = (q_head + q_cnt) % NB; q_cnt++;
                 blk_k0 = k0; blk_g = 0;
                 blk_snap = lds_ld(&s_epoch);               // before anything of usedMap is read for these seeds
+                if (lane == 0) { qk[cur_buf] = k0; qs[cur_buf] = blk_snap; }
                 wg_fence();
                 const int kg = k0 + grp;
                 bool gact = kg < nseeds;
@@ -1281,9 +1365,29 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     blk.n = -1;
                 } else {
                     gid_local++;
-                    grow8(c, gact, gsx, gsy, my_glist, my_gwl, my_gstamp, (uint16_t)(id_base16 + gid_local), g_ring[wave],
-                          b.gcap, g.degThre, blk);
+                    grow8(c, gact, gsx, gsy, wave_glist + ((size_t)cur_buf * NG + grp) * b.gcap, my_gwl, my_gstamp,
+                          (uint16_t)(id_base16 + gid_local), g_ring[wave], b.gcap, g.degThre, blk);
                 }
+                LT(0);
+                continue;
+            } else if (kp >= 0) {
+                // ---- nothing else to do: wait for the turn of the earliest stashed result ----
+                const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
+                while (true) {
+                    advance();
+                    const int f2 = lds_ld(&s_commit);
+                    if (f2 == kp) break;
+                    if (lds_ld(&rg.state[f2 & (RW - 1)]) == R_REDO) break;   // somebody has to redo f2 (top of the loop)
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                tl = (long long)__builtin_amdgcn_s_memtime();
+                STAT(ST_WAIT, tl - tw0);
+                continue;
+            } else {
+                advance();
+                if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
+                __builtin_amdgcn_s_sleep(8);               // nothing left to hand out, or the run-ahead window is full
+                LT(4);
                 continue;
             }
         }
@@ -1291,13 +1395,29 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const uint32_t pp = ord[oidx];
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
-        // ---- evaluate ----
-        if (!from_group) { wg_fence(); }
-        invalidate_tiles(c);
-        const bool skip = from_group ? false : (c.state[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int outcome = 0, num = 0, num0 = 0;
         double logNFA = 0;
         Rec rec;
+        bool skip = false;
+        const uint32_t* m_src = nullptr;                   // stashed pixel list to mark at commit (else the wave's own list)
+        int m_cnt = 0;
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;              // box of everything the evaluation examined
+        if (from_stash) {
+            const int slot = k - st_k0;
+            pend32 &= ~(1u << (8 * st_buf + slot));
+            wg_fence();
+            const double pv = wave_pend[(st_buf * NG + slot) * 24 + (lane < 24 ? lane : 0)];
+            rec.x1 = rl(pv, 0); rec.y1 = rl(pv, 1); rec.x2 = rl(pv, 2); rec.y2 = rl(pv, 3); rec.wid = rl(pv, 4); rec.cX = rl(pv, 5);
+            rec.cY = rl(pv, 6); rec.deg = rl(pv, 7); rec.dx = rl(pv, 8); rec.dy = rl(pv, 9); rec.p = rl(pv, 10); rec.prec = rl(pv, 11);
+            logNFA = rl(pv, 12);
+            rec.pk = (int)rl(pv, 13); outcome = (int)rl(pv, 14); num0 = (int)rl(pv, 15); num = (int)rl(pv, 16); m_cnt = (int)rl(pv, 17);
+            x0 = (int)rl(pv, 18); y0 = (int)rl(pv, 19); x1 = (int)rl(pv, 20); y1 = (int)rl(pv, 21);
+            m_src = wave_glist + ((size_t)st_buf * NG + slot) * b.gcap;
+        } else {
+        // ---- evaluate ----
+        if (!from_group) { wg_fence(); }
+        invalidate_tiles(c);
+        skip = from_group ? false : (c.state[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         bool cur_is_group = false;                         // curMap == the group-mode list (no stamps of this wave)
         if (!skip) {
@@ -1313,15 +1433,18 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     const int src = (k - blk_k0) * 8;
                     num = __builtin_amdgcn_readlane(blk.n, src);
                     gs = rl(blk.sinS, src); gc = rl(blk.cosS, src);
-                    const uint32_t* gl = b.glist + ((img * NW + wave) * NG + (k - blk_k0)) * (size_t)b.gcap;
+                    const uint32_t* gl = wave_glist + ((size_t)cur_buf * NG + (k - blk_k0)) * b.gcap;
                     for (int k2 = lane; k2 < num && k2 < LCAP; k2 += 64) c.lst[k2] = gl[k2];
                     for (int k2 = LCAP + lane; k2 < num; k2 += 64) c.spill[k2 - LCAP] = gl[k2];
                     c.gnum = num; c.has_copy = false;
                     cur_is_group = true;
                     wg_fence();
                 } else {
+                    const long long tg0 = (long long)__builtin_amdgcn_s_memtime();
                     grow(c, sx, sy, seedDeg, tol, num, gs, gc);                       // :225 / :857
                     cur_is_group = false;
+                    if (pass == 0) { STAT(ST_ALLBATCHES, (long long)__builtin_amdgcn_s_memtime() - tg0); STAT(ST_PT2, 1); STAT(ST_PT3, num); }
+
                 }
                 if (pass == 0) {
                     num0 = num;
@@ -1348,6 +1471,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         }
 
         // ---- hand the result over ----
+        LT(1);
         if (spec) {
             if (skip) {
                 if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
@@ -1355,7 +1479,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 continue;
             }
             // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
-            int x0 = fx0, y0 = fy0, x1 = fx1, y1 = fy1;
+            x0 = fx0; y0 = fy0; x1 = fx1; y1 = fy1;
             if (c.has_copy) {                              // RegionRadiusReducer reordered/shrunk lst: use the grow-order copy
                 for (int k2 = lane; k2 < c.gnum; k2 += 64) {
                     const uint32_t pkx = c.gcopy[k2];
@@ -1379,22 +1503,48 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 advance();
                 continue;
             }
-            // marks to make: keep the result and wait for this seed's turn
-            const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
-            bool abandon = false;
-            while (true) {
-                advance();
-                const int f = lds_ld(&s_commit);
-                if (f == k) break;
-                if (lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) { abandon = true; break; }   // somebody has to redo f: me
-                __builtin_amdgcn_s_sleep(4);
+            // marks to make: stash the result (the pixels to mark go to this seed's glist slot) and carry on with the block
+            const int slot = k - blk_k0;
+            uint32_t* gl = wave_glist + ((size_t)cur_buf * NG + slot) * b.gcap;
+            int mcnt = num;                                // a group-mode region that was kept as grown: glist[slot] is the list
+            if (!cur_is_group) {
+                if (c.gnum > b.gcap) {                     // does not fit the slot: evaluate again at the cursor
+                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
+                    STAT(ST_REDO, 1);
+                    advance();
+                    continue;
+                }
+                wg_fence();                                // the stamps written by grow() must have landed
+                c.dirty = false;
+                mcnt = 0;
+                for (int base = 0; base < c.gnum; base += 64) {
+                    const int k2 = base + lane;
+                    uint32_t pkx = 0;
+                    bool keep = false;
+                    if (k2 < c.gnum) {
+                        pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
+                        keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == c.cur_id;   // curMap == 1 only
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) gl[mcnt + __builtin_popcountll(km & ltm)] = pkx;
+                    mcnt += __builtin_popcountll(km);
+                }
             }
-            STAT(ST_WAIT, (long long)__builtin_amdgcn_s_memtime() - tw0);
-            if (abandon) {                                 // give up this result; it is re-evaluated when the cursor gets here
-                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
-                STAT(ST_REDO, 1);
-                continue;
+            if (lane == 0) {
+                double* P = wave_pend + (cur_buf * NG + slot) * 24;
+                P[0] = rec.x1; P[1] = rec.y1; P[2] = rec.x2; P[3] = rec.y2; P[4] = rec.wid; P[5] = rec.cX; P[6] = rec.cY;
+                P[7] = rec.deg; P[8] = rec.dx; P[9] = rec.dy; P[10] = rec.p; P[11] = rec.prec; P[12] = logNFA;
+                P[13] = (double)rec.pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
+                P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
             }
+            wg_fence();
+            pend32 |= 1u << (8 * cur_buf + slot);
+            continue;
+        }
+        }   // !from_stash
+
+        if (spec) {
+            // ---- a stashed result at the cursor (k == s_commit): is it still what the sequential run would get? ----
             wg_fence();
             bool bad = (c.state[pp] & 3u) != 0u;           // an earlier seed marked the pixel meanwhile
             if (bad) {
@@ -1415,7 +1565,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             int bx0, by0, bx1, by1;
             if (outcome == 2) {                                                      // :242-250
-                mark_region(c, 2u, cur_is_group, bx0, by0, bx1, by1);
+                mark_region(c, 2u, m_src, m_cnt, bx0, by0, bx1, by1);
             } else if (outcome == 3) {
                 const int li = s_lines;
                 if (li < b.max_lines && lane == 0) {
@@ -1430,7 +1580,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     double* rs = recs_scaled + (size_t)li * 4;
                     rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
                 }
-                mark_region(c, 1u, cur_is_group, bx0, by0, bx1, by1);                              // :259-265
+                mark_region(c, 1u, m_src, m_cnt, bx0, by0, bx1, by1);                              // :259-265
                 wg_fence();                               // the marks must be visible before the epoch moves
                 if (lane == 0) {
                     const int ep = s_epoch;
@@ -1467,5 +1617,7 @@ void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uin
 int region_groups() { return NW * NG; }
 
 int region_waves() { return NW; }
+
+int region_blocks() { return NB; }
 
 }  // namespace lsdhip

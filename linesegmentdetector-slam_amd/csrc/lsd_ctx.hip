@@ -34,6 +34,9 @@ struct lsd_ctx {
     uint32_t run16 = 0;    // same for the 16-bit group stamps: (run16 << 11) + grow number, run16 in [1, 31]
     uint32_t *glist = nullptr, *gwl = nullptr;
     uint16_t* gstamp = nullptr;
+    double* pend = nullptr;
+    float* wmeta = nullptr;
+    int mcap = 16384;
     int gcap = 16384;
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
@@ -184,13 +187,14 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         HIPCHK(c, re_alloc(&c->sn, tot)); HIPCHK(c, re_alloc(&c->cs, tot));
         HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         const size_t nwv = (size_t)region_waves();
-        HIPCHK(c, re_alloc(&c->spill, tot * nwv)); HIPCHK(c, re_alloc(&c->gcopy, tot * nwv));
+        HIPCHK(c, re_alloc(&c->spill, tot * nwv)); HIPCHK(c, re_alloc(&c->gcopy, tot * nwv)); HIPCHK(c, re_alloc(&c->wmeta, nn * nwv * (size_t)c->mcap * 2));
         HIPCHK(c, re_alloc(&c->stamps, tot * nwv)); HIPCHK(c, re_alloc(&c->seedidx, tot));
         HIPCHK(c, hipMemset(c->stamps, 0, tot * nwv * sizeof(uint32_t)));
         c->run_id = 0;
         const size_t ngr = (size_t)region_groups();
-        HIPCHK(c, re_alloc(&c->glist, nn * ngr * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, nn * ngr * 2 * (size_t)c->gcap));
+        HIPCHK(c, re_alloc(&c->glist, nn * ngr * (size_t)region_blocks() * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, nn * ngr * 2 * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->gstamp, tot * ngr));
+        HIPCHK(c, re_alloc(&c->pend, nn * ngr * (size_t)region_blocks() * 24));
         HIPCHK(c, hipMemset(c->gstamp, 0, tot * ngr * sizeof(uint16_t)));
         c->run16 = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
@@ -266,7 +270,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -317,8 +321,8 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
-    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.stamps = c->stamps; b.seedidx = c->seedidx;
-    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap;
+    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
+    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap; b.pend = c->pend;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;

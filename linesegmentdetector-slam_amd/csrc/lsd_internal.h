@@ -45,12 +45,15 @@ struct Buffers {
     uint32_t* stamps;      // n x NW x npx : per-wave curMap stamps of the region stage
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
+    float* wmeta;          // n x NW x mcap x 2 : per list entry (reference angle, slack) of its last neighbourhood test
+    int mcap;
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
     // group-mode region growing (8 seeds per wavefront): per (image, wave, group) private storage
-    uint32_t* glist;       // n x NW*8 x gcap : region list (grow order)
+    uint32_t* glist;       // n x NW x NB x 8 x gcap : region lists (grow order) of the blocks in flight
     uint32_t* gwl;         // n x NW*8 x 2 x gcap : sweep worklists
     uint16_t* gstamp;      // n x NW*8 x npx : curMap stamps (16-bit generations)
     int gcap;
+    double* pend;          // n x NW x NB x 8 x 24 : finished block results waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
     int32_t* counts;       // n
@@ -80,6 +83,8 @@ void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
 int region_groups();   // seed groups per image (NW * 8)
 int region_waves();
+int region_blocks();   // block buffers per wave (glist and pend are sized x this)
+int region_blocks();
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
