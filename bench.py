@@ -60,7 +60,7 @@ def load_maps():
     return {k: z[k] for k in z.files}
 
 
-def cpu_baseline(maps, size, first, budget_s=12.0, max_images=64):
+def cpu_baseline(maps, size, first, budget_s=15.0, max_images=512):
     """The CPU oracle (a single-threaded port of the reference path) on a bounded sample of the SAME workload."""
     from oracle import oracle
     oracle.build()

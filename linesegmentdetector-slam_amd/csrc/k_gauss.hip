@@ -25,11 +25,14 @@ __device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 
     return cvt_x86(floor(x / sca + 0.5));
 }
 
+// HS > 0: the tap count is a compile-time constant (17 for the reference's sca = 0.3, sig = 0.6): the x-pass keeps its
+// column's taps in registers and both passes are fully unrolled.  HS == 0: any tap count.
+template <int HS>
 __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
                                               const double* __restrict__ taps_g, int W, int H, int w, int h,
                                               double sca, int tapR, int IWp, int IHmax) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int hSize = 2 * tapR + 1;
+    const int hSize = HS > 0 ? HS : 2 * tapR + 1;
     double* aux = reinterpret_cast<double*>(smem);                // [IHmax][TW]
     double* taps = aux + (size_t)IHmax * TW;                      // [3][hSize]
     uint8_t* tile = reinterpret_cast<uint8_t*>(taps + 3 * hSize); // [IHmax][IWp]
@@ -43,23 +46,56 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     const int Xl = min(X0 + TW - 1, w - 1), Yl = min(Y0 + TH - 1, h - 1);
     const int c0 = centre_of(X0, sca) - tapR, c1 = centre_of(Xl, sca) + tapR;
     const int r0 = centre_of(Y0, sca) - tapR, r1 = centre_of(Yl, sca) + tapR;
-    const int IW = c1 - c0 + 1, IH = r1 - r0 + 1;
+    const int IH = r1 - r0 + 1;
 
     for (int i = tid; i < 3 * hSize; i += NT) taps[i] = taps_g[i];
 
-    // stage the source window: lanes walk a row (coalesced), 4 rows per pass
+    // stage the source window as 32-bit words (window columns start at a0 = c0 rounded down to a multiple of 4): every
+    // thread first issues all its loads (up to 16 words in flight), then remaps (myLSD.cpp:135-142) and stores to LDS
+    const int a0 = c0 - (((c0 % 4) + 4) % 4);
     {
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int r = ty; r < IH; r += 4) {
-            const int gy = reflect_idx(r0 + r, H);
-            const uint8_t* row = src + (size_t)gy * W;
-            for (int c = tx; c < IW; c += 64) {
-                const int gx = reflect_idx(c0 + c, W);
-                uint8_t v = row[gx];
-                if (gy >= 1 && gx >= 1) {            // myLSD.cpp:135-142 (row 0 / col 0 keep raw values, Q2)
-                    if (v == 1) v = 255; else if (v == 255) v = 0;
+        const int DW = (c1 - a0 + 4) >> 2;                        // words per window row
+        const int ND = IH * DW;
+        uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
+        const int DWp = IWp >> 2;
+        for (int base = 0; base < ND; base += NT * 16) {
+            uint32_t v[16];
+            #pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int d = base + tid + NT * j;
+                v[j] = 0u;
+                if (d < ND) {
+                    const int r = d / DW, cd = d - r * DW;
+                    const int gy = reflect_idx(r0 + r, H), gx0 = a0 + 4 * cd;
+                    const size_t off = (size_t)gy * W + gx0;
+                    if (gx0 >= 0 && gx0 + 3 < W && (off & 3) == 0) v[j] = *reinterpret_cast<const uint32_t*>(src + off);
+                    else {
+                        #pragma unroll
+                        for (int k2 = 0; k2 < 4; k2++) v[j] |= (uint32_t)src[(size_t)gy * W + reflect_idx(gx0 + k2, W)] << (8 * k2);
+                    }
                 }
-                tile[r * IWp + c] = v;
+            }
+            #pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int d = base + tid + NT * j;
+                if (d < ND) {
+                    const int r = d / DW, cd = d - r * DW;
+                    const int gy = reflect_idx(r0 + r, H), gx0 = a0 + 4 * cd;
+                    uint32_t x = v[j];
+                    // bytes == 1 -> 255, bytes == 255 -> 0; row 0 and column 0 keep their raw values (Q2)
+                    uint32_t t1 = x ^ 0x01010101u, t2 = ~x;       // zero bytes mark the two cases
+                    t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
+                    t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
+                    uint32_t m1 = (t1 >> 7) * 255u, m255 = (t2 >> 7) * 255u;
+                    uint32_t keep = 0u;                            // bytes exempt from the remap
+                    if (gy == 0) keep = 0xffffffffu;
+                    else {
+                        #pragma unroll
+                        for (int k2 = 0; k2 < 4; k2++) if (reflect_idx(gx0 + k2, W) == 0) keep |= 0xffu << (8 * k2);
+                    }
+                    m1 &= ~keep; m255 &= ~keep;
+                    tile32[r * DWp + cd] = (x | m1) & ~m255;
+                }
             }
         }
     }
@@ -69,14 +105,27 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     const int X = tid & (TW - 1);
     const int gX = X0 + X;
     {
-        const int cb = centre_of(gX, sca) - tapR - c0;            // first tap's column inside the window
+        const int cb = centre_of(gX, sca) - tapR - a0;            // first tap's column inside the window
         const double* ker = taps + (gX % 3) * hSize;
         if (gX < w) {
-            for (int r = tid / TW; r < IH; r += NT / TW) {
-                const uint8_t* t = tile + r * IWp + cb;
-                double v = 0;
-                for (int i = 0; i < hSize; i++) v += (double)(int)t[i] * ker[i];
-                aux[r * TW + X] = v;
+            if (HS > 0) {
+                double kr[HS > 0 ? HS : 1];
+                #pragma unroll
+                for (int i = 0; i < HS; i++) kr[i] = ker[i];
+                for (int r = tid / TW; r < IH; r += NT / TW) {
+                    const uint8_t* t = tile + r * IWp + cb;
+                    double v = 0;
+                    #pragma unroll
+                    for (int i = 0; i < HS; i++) v += (double)(int)t[i] * kr[i];
+                    aux[r * TW + X] = v;
+                }
+            } else {
+                for (int r = tid / TW; r < IH; r += NT / TW) {
+                    const uint8_t* t = tile + r * IWp + cb;
+                    double v = 0;
+                    for (int i = 0; i < hSize; i++) v += (double)(int)t[i] * ker[i];
+                    aux[r * TW + X] = v;
+                }
             }
         }
     }
@@ -90,7 +139,12 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
             const int rb = centre_of(gY, sca) - tapR - r0;
             const double* ker = taps + (gY % 3) * hSize;
             double v = 0;
-            for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
+            if (HS > 0) {
+                #pragma unroll
+                for (int i = 0; i < HS; i++) v += aux[(rb + i) * TW + X] * ker[i];
+            } else {
+                for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
+            }
             dst[(size_t)gY * w + gX] = v;
         }
     }
@@ -114,16 +168,15 @@ __global__ __launch_bounds__(256) void k_remap_inplace(uint8_t* __restrict__ img
 void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const int span = (int)floor((TW - 1) / g.sca) + 2;            // bound on centre(X0+31) - centre(X0) + 1
     const int IWmax = span + 2 * g.tapR + 1;
-    const int IWp = (IWmax + 3) & ~3;
+    const int IWp = ((IWmax + 3) & ~3) + 4;                       // + the alignment slack of the word-wise staging
     const int IHmax = IWmax;
     const int hSize = 2 * g.tapR + 1;
     const size_t lds = (size_t)IHmax * TW * sizeof(double) + 3 * hSize * sizeof(double) + (size_t)IHmax * IWp;
+    auto kern = hSize == 17 ? k_gauss<17> : k_gauss<0>;
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((g.w + TW - 1) / TW, (g.h + TH - 1) / TH, n);
-    hipLaunchKernelGGL(k_gauss, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.sca, g.tapR,
-                       IWp, IHmax);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.sca, g.tapR, IWp, IHmax);
 }
 
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {

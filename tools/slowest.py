@@ -21,7 +21,7 @@ tot = np.array([x["cycles_total"] for x in st]) / 1e6
 print("Mcycles total: mean %.0f median %.0f p90 %.0f max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
 for i in np.argsort(-tot)[:6]:
     x = st[i]
-    print(i, "src", bench.SOURCES[i % 4], "flip", (i // 4) % 4, {k: (v // 1000000 if k.startswith("cycles") or k in ("pt_pick", "pt_reads", "pt_commit", "pt_worklist", "all_batches") else v) for k, v in x.items()})
+    print(i, "src", bench.SOURCES[i % 4], "flip", (i // 4) % 4, {k: (v // 1000000 if k.startswith("cycles") or k in ("pt_pick", "pt_reads", "pt_commit", "pt_worklist", "all_batches", "_r23") else v) for k, v in x.items()})
 print("per source: n, mean/max Mcycles total, then mean wave-Mcycles of wait / grow8 / eval / idle")
 for si, name in enumerate(bench.SOURCES):
     idx = [i for i in range(n) if i % 4 == si]
