@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="images per GPU")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, single-image latency, copy ceiling): what the profiling passes use")
     ap.add_argument("--no-lineim", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
     a = ap.parse_args()
@@ -194,6 +194,28 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms},
         }
+        if world == 1 and not a.no_cpu_baseline:
+            # extras outside the timed region: single-image latency, and the device-copy ceiling of this box
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lat = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.enqueue_device(d_maps.data_ptr(), 1, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(),
+                                   d_line_ims=None if d_ims is None else d_ims.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            out["single_image_latency_ms"] = min(lat)
+            src_t = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            dst_t = torch.empty_like(src_t)
+            dst_t.copy_(src_t)
+            ev0.record()
+            for _ in range(5):
+                dst_t.copy_(src_t)
+            ev1.record()
+            torch.cuda.synchronize()
+            out["roofline"]["measured_copy_GBs"] = 5 * 2 * (1 << 30) / (ev0.elapsed_time(ev1) * 1e-3) / 1e9   # read + write
+            del src_t, dst_t
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(maps, size, first)
         print(json.dumps(out), flush=True)

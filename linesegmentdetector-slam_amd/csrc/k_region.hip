@@ -493,8 +493,14 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
 // row-major), sums accumulated in that order, estimate + rigorous margin with exact fallback, worklist sweeps.
 // ---------------------------------------------------------------------------------------------
 constexpr int NG = 8;
-constexpr int G8_MIN_STEPS = 24;    // group mode always runs this many steps ...
-constexpr int G8_MIN_ACTIVE = 3;    // ... and goes on while at least this many of the 8 regions are still growing
+#ifndef LSD_G8_MIN_STEPS
+#define LSD_G8_MIN_STEPS 24
+#endif
+#ifndef LSD_G8_MIN_ACTIVE
+#define LSD_G8_MIN_ACTIVE 3
+#endif
+constexpr int G8_MIN_STEPS = LSD_G8_MIN_STEPS;    // group mode always runs this many steps ...
+constexpr int G8_MIN_ACTIVE = LSD_G8_MIN_ACTIVE;  // ... and goes on while at least this many of the 8 regions are still growing
 
 struct G8 {                      // per-lane results (identical within a group)
     int n;                       // region size; -1: list capacity exceeded (caller falls back to grow())

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Derives profiles/traffic_latest.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
+
+usage: pmc_to_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json]
+Counters are KB per dispatch.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the factor 2 on FETCH_SIZE is
+the gfx950 correction of MI355X_MICROARCH.md, confirmed for this code's 8-B-per-lane loads with tools/pmc_calib.py."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+KERNELS = ("k_gauss", "k_gradient", "k_sort", "k_region", "k_lines")
+
+
+def per_kernel(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            for k in KERNELS:
+                if k in row["Kernel_Name"]:
+                    acc[k].append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    fd, wd = sys.argv[1], sys.argv[2]
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
+    f, nf = per_kernel(fd, "FETCH_SIZE")
+    w, nw = per_kernel(wd, "WRITE_SIZE")
+    res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
+           "--no-cpu-baseline` (512 x 2048^2); counters are KB per dispatch, averaged over the launches of each kernel; "
+           "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (confirmed for 8-B-per-lane loads with "
+           "tools/pmc_calib.py: profiles/r01b_pmc_calib_*.csv)",
+           "kernels": {}}
+    for k in KERNELS:
+        if k in f and k in w:
+            res["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k], "launches": [nf[k], nw[k]],
+                                 "hbm_bytes_per_launch": (2 * f[k] + w[k]) * 1024}
+    res["k_gradient_bytes_per_launch"] = res["kernels"].get("k_gradient", {}).get("hbm_bytes_per_launch")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
