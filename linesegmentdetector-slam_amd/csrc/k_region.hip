@@ -1282,7 +1282,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NB * NG * 24;
     const unsigned long long ltm = (1ull << lane) - 1ull;
     long long tl = (long long)__builtin_amdgcn_s_memtime();
+#ifdef LSD_PROFILE_GROW
+#define LT(i) do { (void)tl; } while (0)
+#else
 #define LT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT(ST_PT0 + (i), t_ - tl); tl = t_; } while (0)
+#endif
     while (true) {
         // ---- choose the next job ----
         int k;

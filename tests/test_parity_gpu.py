@@ -326,18 +326,24 @@ def test_cpp_adapter_runs(maps, tmp_path):
         'int main(int argc, char** argv) {\n'
         '  mylsd::Mat m = mylsd::make_u8(480, 608);\n'
         '  FILE* f = fopen(argv[1], "rb"); size_t n = fread(m.ptr<unsigned char>(0), 1, 480*608, f); fclose(f);\n'
+        '  mylsd::MatF64 mc = mylsd::createMapCache(m, 0.05);   /* before the LSD call: it rewrites m (Q2) */\n'
+        '  double msum = 0; long below = 0; for (int y = 0; y < 480; y++) for (int x = 0; x < 608; x++) { double v = mc.ptr<double>(y)[x]; msum += v; below += v < 1.0; }\n'
         '  mylsd::structLSD r = mylsd::myLineSegmentDetector(m, 608, 480, lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin);\n'
         '  long lit = 0; for (int y = 0; y < 480; y++) for (int x = 0; x < 608; x++) lit += r.lineIm.ptr<unsigned char>(y)[x] == 255;\n'
-        '  std::printf("%zu %d %ld %.17g %d\\n", n, r.len_linesInfo, lit, r.linesInfo[0].x1, (int)m.ptr<unsigned char>(3)[3]);\n'
+        '  std::printf("%zu %d %ld %.17g %d %.6f %ld\\n", n, r.len_linesInfo, lit, r.linesInfo[0].x1, (int)m.ptr<unsigned char>(3)[3], msum, below);\n'
+        '  int bad = 0; try { mylsd::myLineSegmentDetector(mylsd::make_u8(2, 2), 2, 2, 0.3, 0.6, 22.5, 0.7, 1024); } catch (const mylsd::lsd_error& e) { bad = e.status; }\n'
+        '  std::printf("%d\\n", bad);\n'
         '  free(r.linesInfo); return 0; }\n')
     exe = tmp_path / "t"
     subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
                     "-L", pkg, "-llsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     p = subprocess.run([str(exe), str(raw)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
-    n, nl, lit, x1, _ = p.stdout.split()
+    n, nl, lit, x1, _, msum, below, bad = p.stdout.split()
     assert int(n) == 480 * 608 and int(nl) == 7 and int(lit) == 545
     assert abs(float(x1) - 351.00301936775691) < ENDPOINT_TOL
+    assert abs(float(msum) - 281563.372994) < 1e-5 and int(below) == 20064        # SURVEY 8c, map1 mapCache
+    assert int(bad) == 1                                                           # LSD_ERR_INVALID surfaces as lsd_error
 
 
 # ---- createMapCache: integer flood order + exactly rounded sqrt -> BIT-EXACT --------------
@@ -385,3 +391,32 @@ def test_map_cache_device_batch(maps, lsdmod, ctx, oracle):
     for i in range(3):
         assert np.array_equal(out[i].cpu().numpy(), oracle.map_cache(batch[i].copy(), 0.025))
     assert np.array_equal(d.cpu().numpy(), batch)
+
+
+# ---- error behaviour of the C ABI (the reference has none: it would crash) -----------------------------------
+def test_error_codes(maps, lsdmod, ctx):
+    import ctypes
+    L, h = ctx.L, ctx.h
+    img = maps["map1"].copy()
+    rows, cols = img.shape
+    P = lsdmod.make_params()
+    lines = ctypes.c_void_p()
+    n = ctypes.c_int(-1)
+    call = lambda im, c_, r_, st, pp: L.lsd_run(h, im, c_, r_, st, ctypes.byref(pp), None, 0, ctypes.byref(lines), ctypes.byref(n))
+    assert call(None, cols, rows, cols, P) == lsdmod.LSD_ERR_INVALID
+    assert call(img.ctypes.data, cols, rows, cols - 1, P) == lsdmod.LSD_ERR_INVALID          # stride < cols
+    assert call(img.ctypes.data, 0, rows, cols, P) == lsdmod.LSD_ERR_INVALID
+    assert call(img.ctypes.data, 3, 3, 3, P) == lsdmod.LSD_ERR_INVALID                        # scaled size below 2x2
+    assert call(img.ctypes.data, 70000, 4, 70000, P) == lsdmod.LSD_ERR_UNSUPPORTED            # coordinates are packed in 16 bits
+    for field, val, want in (("pseBin", 2048, lsdmod.LSD_ERR_UNSUPPORTED), ("pseBin", 0, lsdmod.LSD_ERR_INVALID),
+                             ("sca", 0.0, lsdmod.LSD_ERR_INVALID), ("sig", -1.0, lsdmod.LSD_ERR_INVALID)):
+        Q = lsdmod.make_params()
+        setattr(Q, field, val)
+        assert call(img.ctypes.data, cols, rows, cols, Q) == want, field
+    assert np.array_equal(img, maps["map1"])                                      # a refused call leaves the map untouched
+    out = np.zeros((rows, cols))
+    assert L.lsd_map_cache(h, img.ctypes.data, cols, rows, cols, 0.0, 1.0, out.ctypes.data) == lsdmod.LSD_ERR_INVALID
+    assert L.lsd_map_cache(h, None, cols, rows, cols, 0.05, 1.0, out.ctypes.data) == lsdmod.LSD_ERR_INVALID
+    assert L.lsd_strerror(lsdmod.LSD_ERR_UNSUPPORTED) and L.lsd_last_error(h) is not None
+    got_lines, _ = ctx.run(img)                                                   # and the context is still usable
+    assert len(got_lines) == 7
