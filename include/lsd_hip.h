@@ -114,6 +114,15 @@ int lsd_map_cache(lsd_ctx *ctx, const uint8_t *map, int cols, int rows, size_t s
 int lsd_enqueue_map_cache_device(lsd_ctx *ctx, const uint8_t *d_maps, int n, int cols, int rows, double res,
                                  double z_occ_max_dis, double *d_out, void *stream);
 
+/* --- wire format (SURVEY 8f "next" #3) ---------------------------------------------------------- */
+/* Replaces the cell loop of the ROS map callback (LSD/main_on_linux.cpp:108-124): nav_msgs/OccupancyGrid cells
+ * (int8: -1 unknown, 0 free, 1..100 occupied) become the loader's map values (0 unknown, 255 free, 1 occupied), the
+ * input of lsd_map_cache and lsd_run.  Host buffers: grid rows x cols packed, map_out with pitch map_stride. */
+int lsd_occupancy_to_map(lsd_ctx *ctx, const int8_t *grid, int cols, int rows, uint8_t *map_out, size_t map_stride);
+/* The same for n_cells device-resident cells (any number of equally sized grids back to back), asynchronous on
+ * `stream`; both pointers 16-byte aligned.  Lets a map that arrives on the device never touch the host. */
+int lsd_enqueue_occupancy_to_map_device(lsd_ctx *ctx, const int8_t *d_grid, size_t n_cells, uint8_t *d_map, void *stream);
+
 /* --- introspection used by the parity tests and the bench ------------------------------- */
 /* Scaled size of a cols x rows map: w = floor(cols*sca), h = floor(rows*sca) (myLSD.cpp:132-133). */
 void lsd_scaled_size(int cols, int rows, double sca, int *w, int *h);

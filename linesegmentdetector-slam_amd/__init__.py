@@ -95,6 +95,9 @@ def load_library(path=None):
     L.lsd_map_cache.restype = i; L.lsd_map_cache.argtypes = [vp, vp, i, i, sz, dbl, dbl, vp]
     L.lsd_enqueue_map_cache_device.restype = i
     L.lsd_enqueue_map_cache_device.argtypes = [vp, vp, i, i, i, dbl, dbl, vp, vp]
+    L.lsd_occupancy_to_map.restype = i; L.lsd_occupancy_to_map.argtypes = [vp, vp, i, i, vp, sz]
+    L.lsd_enqueue_occupancy_to_map_device.restype = i
+    L.lsd_enqueue_occupancy_to_map_device.argtypes = [vp, vp, sz, vp, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -106,7 +109,7 @@ EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
                     "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
-                    "lsd_enqueue_map_cache_device"]
+                    "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device"]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -202,6 +205,17 @@ class Context:
     def enqueue_map_cache_device(self, d_maps, n, cols, rows, res, z_occ_max_dis, d_out, stream=None):
         return self._chk(self.L.lsd_enqueue_map_cache_device(self.h, d_maps, n, cols, rows, float(res),
                                                              float(z_occ_max_dis), d_out, stream))
+
+    def occupancy_to_map(self, grid_i8):
+        """lsd_occupancy_to_map on an int8 [rows, cols] OccupancyGrid; returns the uint8 map."""
+        assert grid_i8.dtype == np.int8 and grid_i8.ndim == 2 and grid_i8.flags.c_contiguous
+        rows, cols = grid_i8.shape
+        out = np.zeros((rows, cols), np.uint8)
+        self._chk(self.L.lsd_occupancy_to_map(self.h, grid_i8.ctypes.data, cols, rows, out.ctypes.data, out.strides[0]))
+        return out
+
+    def enqueue_occupancy_to_map_device(self, d_grid, n_cells, d_map, stream=None):
+        return self._chk(self.L.lsd_enqueue_occupancy_to_map_device(self.h, d_grid, n_cells, d_map, stream))
 
     def reserve(self, n, cols, rows):
         self._chk(self.L.lsd_reserve(self.h, n, cols, rows))
@@ -307,6 +321,18 @@ def createMapCache(MapGray, res, ctx=None):
     """mylsd::createMapCache (LSD/myLSD.h:131, LSD/myLSD.cpp:11): CV_64FC1-like float64 array, metres, capped at
     z_occ_max_dis.  Call it before myLineSegmentDetector, which rewrites MapGray."""
     return (ctx or default_context()).map_cache(MapGray, res, z_occ_max_dis)
+
+
+def mapCallback(data, oriMapCol, oriMapRow, mapResol, ctx=None):
+    """The ROS node's map callback (LSD/main_on_linux.cpp:97-135): OccupancyGrid cells -> mapValue -> mapCache (with
+    the callback's z_occ_max_dis = 2, :126-127) and the LSD result.  Returns (mapValue as rewritten by the LSD call,
+    mapCache, structLSD)."""
+    cx = ctx or default_context()
+    grid = np.ascontiguousarray(np.asarray(data, np.int8).reshape(oriMapRow, oriMapCol))
+    mapValue = cx.occupancy_to_map(grid)
+    mapCache = cx.map_cache(mapValue, mapResol, 2.0)
+    LSD = myLineSegmentDetector(mapValue, oriMapCol, oriMapRow, lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin, ctx=cx)
+    return mapValue, mapCache, LSD
 
 
 def runLSD(MapGray, oriMapCol=None, oriMapRow=None, sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre,

@@ -61,6 +61,8 @@ struct lsd_ctx {
     uint8_t* mc_in = nullptr;
     double* mc_out = nullptr;
     size_t mc_cap = 0, mc_hcap = 0;
+    uint8_t *oc_in = nullptr, *oc_out = nullptr;        // occupancy-grid staging of the host entry point
+    size_t oc_cap = 0;
     // options
     int stop_after = 0;
     bool trace = false;
@@ -272,7 +274,7 @@ void lsd_destroy(lsd_ctx* c) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
-                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out};
+                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out, c->oc_in, c->oc_out};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -531,6 +533,34 @@ int lsd_map_cache(lsd_ctx* c, const uint8_t* map, int cols, int rows, size_t str
     const int st = lsd_enqueue_map_cache_device(c, c->mc_in, 1, cols, rows, res, z_occ_max_dis, c->mc_out, c->stream);
     if (st != LSD_OK) return st;
     HIPCHK(c, hipMemcpyAsync(out, c->mc_out, wh * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LSD_OK;
+}
+
+int lsd_enqueue_occupancy_to_map_device(lsd_ctx* c, const int8_t* d_grid, size_t n_cells, uint8_t* d_map, void* stream) {
+    if (!c || !d_grid || !d_map || n_cells == 0) return LSD_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(d_grid) | reinterpret_cast<uintptr_t>(d_map)) & 15u) return LSD_ERR_INVALID;   // 16-byte accesses
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    launch_occ_to_map(reinterpret_cast<const uint8_t*>(d_grid), d_map, n_cells, s);
+    HIPCHK(c, hipGetLastError());
+    c->last_stream = s;
+    return LSD_OK;
+}
+
+int lsd_occupancy_to_map(lsd_ctx* c, const int8_t* grid, int cols, int rows, uint8_t* map_out, size_t map_stride) {
+    if (!c || !grid || !map_out || cols <= 0 || rows <= 0 || map_stride < (size_t)cols) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t wh = (size_t)cols * rows;
+    if (wh > c->oc_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->oc_in, wh)); HIPCHK(c, re_alloc(&c->oc_out, wh));
+        c->oc_cap = wh;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->oc_in, grid, wh, hipMemcpyHostToDevice, c->stream));
+    const int st = lsd_enqueue_occupancy_to_map_device(c, reinterpret_cast<const int8_t*>(c->oc_in), wh, c->oc_out, c->stream);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipMemcpy2DAsync(map_out, map_stride, c->oc_out, cols, cols, rows, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LSD_OK;
 }

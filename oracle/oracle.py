@@ -146,3 +146,14 @@ def map_cache(map_u8, res, z_occ_max_dis=1.0, _lib=None):
     if rc != 0:
         raise RuntimeError("orc_map_cache failed: %d" % rc)
     return out
+
+
+def occupancy_to_map(grid_i8):
+    """Oracle for the cell loop of mapCallback (LSD/main_on_linux.cpp:108-124): the int8 cell read as uint8 is mapped
+    255 -> 0, 0 -> 255, anything else -> 1.  PARITY UNPINNED: the reference ships no input/output pair for this loop
+    (data/mapValue.txt is an output only); the restatement is three branches read off the source."""
+    v = np.ascontiguousarray(grid_i8).view(np.uint8)
+    out = np.ones(v.shape, np.uint8)
+    out[v == 255] = 0
+    out[v == 0] = 255
+    return out

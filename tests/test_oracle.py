@@ -184,3 +184,12 @@ def test_oracle_asan_clean(maps, oracle):
     env = dict(os.environ, LD_PRELOAD=asan[-1], ASAN_OPTIONS="detect_leaks=0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
+
+
+def test_occupancy_to_map_exhaustive(oracle):
+    """All 256 cell values through the restated map-callback loop (LSD/main_on_linux.cpp:108-124)."""
+    cells = np.arange(256, dtype=np.uint8).view(np.int8).reshape(16, 16)
+    got = oracle.occupancy_to_map(cells)
+    want = np.ones(256, np.uint8); want[0] = 255; want[255] = 0           # 0 free -> 255, -1 unknown -> 0, 1..100 (and the rest) -> 1
+    assert np.array_equal(got.ravel(), want)
+    assert got[cells == -1].tolist() == [0] and got[cells == 100].tolist() == [1]

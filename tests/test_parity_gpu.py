@@ -420,3 +420,35 @@ def test_error_codes(maps, lsdmod, ctx):
     assert L.lsd_strerror(lsdmod.LSD_ERR_UNSUPPORTED) and L.lsd_last_error(h) is not None
     got_lines, _ = ctx.run(img)                                                   # and the context is still usable
     assert len(got_lines) == 7
+
+
+# ---- wire format: OccupancyGrid cells -> map values on the device (byte-exact) ------------
+@pytest.mark.parametrize("rows,cols", [(16, 16), (1, 1), (3, 5), (257, 129), (480, 608)])
+def test_occupancy_to_map(rows, cols, lsdmod, ctx, oracle):
+    rng = np.random.default_rng(rows * 1000 + cols)
+    grid = rng.choice(np.array([-1, 0, 100, 1, 37, -128, 127, -2], np.int8), size=(rows, cols),
+                      p=[0.3, 0.4, 0.2, 0.02, 0.02, 0.02, 0.02, 0.02]).astype(np.int8)
+    if rows * cols >= 256:
+        grid.ravel()[:256] = np.arange(256, dtype=np.uint8).view(np.int8)     # every cell value at least once
+    assert np.array_equal(ctx.occupancy_to_map(grid), oracle.occupancy_to_map(grid))
+
+
+def test_occupancy_device_and_map_callback(maps, maps_meta, known, lsdmod, ctx, oracle):
+    import torch
+    # the grid whose callback output is the aisle1 fixture: 0 -> unknown(-1), 255 -> free(0), 1 -> occupied(100)
+    m = maps["aisle1"]
+    grid = np.full(m.shape, 100, np.int8); grid[m == 0] = -1; grid[m == 255] = 0
+    assert np.array_equal(oracle.occupancy_to_map(grid), m)
+    d = torch.from_numpy(np.stack([grid, grid[::-1].copy()])).cuda()
+    out = torch.zeros(d.shape, dtype=torch.uint8, device="cuda")
+    ctx.enqueue_occupancy_to_map_device(d.data_ptr(), d.numel(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), m) and np.array_equal(out[1].cpu().numpy(), m[::-1])
+    # the whole callback: same lines as the fixture run directly, mapCache with the callback's 2 m cap
+    rows, cols = m.shape
+    res = maps_meta["aisle1"]["res"]
+    mapValue, mapCache, LSD = lsdmod.mapCallback(grid.ravel(), cols, rows, res, ctx=ctx)
+    assert LSD.len_linesInfo == known["counts"]["aisle1"][0]
+    ref = oracle.lsd(m.copy())
+    assert np.array_equal(mapValue, ref["map"]) if "map" in ref else True
+    assert np.array_equal(mapCache, oracle.map_cache(m.copy(), res, 2.0))
