@@ -173,11 +173,13 @@ def main():
         grad_ms = kt["gradient"] / a.steps
         grad_bytes = GRAD_BYTES_PER_PX * w * h * n
         achieved = grad_bytes / (grad_ms * 1e-3) / 1e9 if grad_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_all = None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_gradient_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_gradient_bytes_per_launch")
+                traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items()}
             except Exception:
                 traffic = None
         out = {
@@ -190,6 +192,10 @@ def main():
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU"},
             "lines_per_s": total_lines / (dt / a.steps), "lines_per_step": total_lines, "line_overflow_images": overflow,
             "kernel_ms": {k: v / a.steps for k, v in kt.items()},
+            # informational: every kernel's HBM traffic (PMC, profiles/traffic_latest.json) over its live launch time
+            "kernel_hbm_GBs": {k: traffic_all["k_" + k] / (kt[k] / a.steps * 1e-3) / 1e9
+                               for k in ("gauss", "gradient", "sort", "region", "lines")
+                               if n == 512 and size == 2048 and ("k_" + k) in traffic_all and kt[k] > 0},
             "roofline": {"kernel": "k_gradient", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms},
