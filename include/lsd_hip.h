@@ -114,6 +114,29 @@ int lsd_map_cache(lsd_ctx *ctx, const uint8_t *map, int cols, int rows, size_t s
 int lsd_enqueue_map_cache_device(lsd_ctx *ctx, const uint8_t *d_maps, int n, int cols, int rows, double res,
                                  double z_occ_max_dis, double *d_out, void *stream);
 
+/* --- scan-to-map matching batch (SURVEY 8f "next" #2) ------------------------------------------- */
+/* Replaces the body of myfa::thread_ScanToMapMatch (LSD/myFA.cpp:197-270) with NormalizedLineDirection (:272-305),
+ * rotateScanIm (:307-357) and CalcScore (:359-396), which the reference runs once per (map line, scan line) pair on a
+ * 30-thread pool.  For pair p = {cntMapLine, cntScanLine} and matching i = 1..4 (:205-249)
+ *   out[4 * p + i - 1] = { rotated lidar pose (x, y, angDiff in (-180, 180]), score }
+ * with score = INFINITY where rotateScanIm rejects the candidate (farther than max_esti_dist from last_pose, :330) or
+ * CalcScore does (:388).  The caller keeps score < 3 and sorts, as FeatureAssociation does (:60-100).
+ * lsd_position == structPosition (LSD/baseFunc.h:46-50); lines are structLinesInfo; map_cache is the rows x cols
+ * CV_64FC1 array of lsd_map_cache.  Scores agree with the reference arithmetic up to the libm caveat of lsd_run. */
+typedef struct lsd_position { double x, y, ang; } lsd_position;
+typedef struct lsd_match_score { lsd_position pos; double score; } lsd_match_score;
+int lsd_scan_to_map_match(lsd_ctx *ctx, const double *map_cache, int cols, int rows,
+                          const lsd_line *map_lines, int n_map, const lsd_line *scan_lines, int n_scan,
+                          const lsd_position *scan_im_points, int n_points, lsd_position lidar_pose, lsd_position last_pose,
+                          const int *pairs, int n_pairs, double z_occ_max_dis, double max_esti_dist, lsd_match_score *out);
+/* The same with every array resident on the device (d_map_cache as written by lsd_enqueue_map_cache_device), asynchronous
+ * on `stream`; pair indices are NOT range-checked here. */
+int lsd_enqueue_scan_to_map_match_device(lsd_ctx *ctx, const double *d_map_cache, int cols, int rows,
+                                         const lsd_line *d_map_lines, const lsd_line *d_scan_lines,
+                                         const lsd_position *d_scan_im_points, int n_points, lsd_position lidar_pose,
+                                         lsd_position last_pose, const int *d_pairs, int n_pairs, double z_occ_max_dis,
+                                         double max_esti_dist, lsd_match_score *d_out, void *stream);
+
 /* --- wire format (SURVEY 8f "next" #3) ---------------------------------------------------------- */
 /* Replaces the cell loop of the ROS map callback (LSD/main_on_linux.cpp:108-124): nav_msgs/OccupancyGrid cells
  * (int8: -1 unknown, 0 free, 1..100 occupied) become the loader's map values (0 unknown, 255 free, 1 occupied), the

@@ -46,6 +46,14 @@ SEED_DTYPE = np.dtype([("order_idx", "i4"), ("x", "i4"), ("y", "i4"), ("num", "i
 assert LINE_DTYPE.itemsize == 80 == C.sizeof(lsd_line)
 
 
+class lsd_position(C.Structure):  # == structPosition, LSD/baseFunc.h:46-50
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("ang", C.c_double)]
+
+
+POS_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("ang", "f8")])
+SCORE_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("ang", "f8"), ("score", "f8")])   # lsd_match_score
+
+
 class LsdError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("lsd_hip status %d: %s" % (status, msg))
@@ -98,6 +106,10 @@ def load_library(path=None):
     L.lsd_occupancy_to_map.restype = i; L.lsd_occupancy_to_map.argtypes = [vp, vp, i, i, vp, sz]
     L.lsd_enqueue_occupancy_to_map_device.restype = i
     L.lsd_enqueue_occupancy_to_map_device.argtypes = [vp, vp, sz, vp, vp]
+    L.lsd_scan_to_map_match.restype = i
+    L.lsd_scan_to_map_match.argtypes = [vp, vp, i, i, vp, i, vp, i, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp]
+    L.lsd_enqueue_scan_to_map_match_device.restype = i
+    L.lsd_enqueue_scan_to_map_match_device.argtypes = [vp, vp, i, i, vp, vp, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -109,7 +121,8 @@ EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
                     "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
-                    "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device"]
+                    "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
+                    "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device"]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -205,6 +218,22 @@ class Context:
     def enqueue_map_cache_device(self, d_maps, n, cols, rows, res, z_occ_max_dis, d_out, stream=None):
         return self._chk(self.L.lsd_enqueue_map_cache_device(self.h, d_maps, n, cols, rows, float(res),
                                                              float(z_occ_max_dis), d_out, stream))
+
+    def scan_to_map_match(self, map_cache, map_lines, scan_lines, scan_im_points, lidar_pose, last_pose, pairs,
+                          z_occ=1.0, max_esti_dist=60.0):
+        """lsd_scan_to_map_match: map_cache float64 [rows, cols]; lines LINE_DTYPE arrays; scan_im_points POS_DTYPE (or
+        [n, 3] float64); poses (x, y[, ang]); pairs int32 [m, 2] = (cntMapLine, cntScanLine).  Returns SCORE_DTYPE [m, 4]."""
+        mc = np.ascontiguousarray(map_cache, np.float64)
+        rows, cols = mc.shape
+        ml = np.ascontiguousarray(map_lines, LINE_DTYPE); sl = np.ascontiguousarray(scan_lines, LINE_DTYPE)
+        pts = np.ascontiguousarray(scan_im_points).view(np.float64).reshape(-1, 3)
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        out = np.zeros((len(pr), 4), SCORE_DTYPE)
+        mk = lambda p: lsd_position(float(p[0]), float(p[1]), float(p[2]) if len(p) > 2 else 0.0)
+        self._chk(self.L.lsd_scan_to_map_match(self.h, mc.ctypes.data, cols, rows, ml.ctypes.data, len(ml), sl.ctypes.data, len(sl),
+                                               pts.ctypes.data, len(pts), mk(lidar_pose), mk(last_pose), pr.ctypes.data, len(pr),
+                                               float(z_occ), float(max_esti_dist), out.ctypes.data))
+        return out
 
     def occupancy_to_map(self, grid_i8):
         """lsd_occupancy_to_map on an int8 [rows, cols] OccupancyGrid; returns the uint8 map."""
@@ -321,6 +350,39 @@ def createMapCache(MapGray, res, ctx=None):
     """mylsd::createMapCache (LSD/myLSD.h:131, LSD/myLSD.cpp:11): CV_64FC1-like float64 array, metres, capped at
     z_occ_max_dis.  Call it before myLineSegmentDetector, which rewrites MapGray."""
     return (ctx or default_context()).map_cache(MapGray, res, z_occ_max_dis)
+
+
+# FeatureAssociation constants, LSD/baseFunc.h:80-86
+ignoreScanLength, scanToMapDiff, maxEstiDist = 40, 0.35, 60
+
+
+def match_pairs(map_lines, scan_lines):
+    """The (cntMapLine, cntScanLine) pairs FeatureAssociation hands to its thread pool (LSD/myFA.cpp:28-58), in its order."""
+    pairs = []
+    for cs in range(len(scan_lines)):
+        ls = float(scan_lines["len"][cs])
+        if ls < ignoreScanLength:
+            continue
+        ld = ls * scanToMapDiff
+        for cm in range(len(map_lines)):
+            lm = float(map_lines["len"][cm])
+            if lm < ls - ld or lm > ls + ld:
+                continue
+            pairs.append((cm, cs))
+    return np.array(pairs, np.int32).reshape(-1, 2)
+
+
+def ScanToMapMatch(mapCache, mapLinesInfo, scanLinesInfo, scanImPoint, lidarPose, lastPose, ctx=None):
+    """The matching stage of myfa::FeatureAssociation (LSD/myFA.cpp:28-100): every admissible (scan line, map line) pair x 4
+    matchings scored on the device, candidates with score < 3 kept (:262) and sorted by score (:98, CompScore :398-402).
+    Returns SCORE_DTYPE records (the reference's structScore without the debug pointer)."""
+    pairs = match_pairs(mapLinesInfo, scanLinesInfo)
+    if len(pairs) == 0:
+        return np.zeros(0, SCORE_DTYPE)
+    sc = (ctx or default_context()).scan_to_map_match(mapCache, mapLinesInfo, scanLinesInfo, scanImPoint, lidarPose, lastPose, pairs,
+                                                      z_occ_max_dis, maxEstiDist).ravel()
+    keep = sc[sc["score"] < 3]
+    return keep[np.argsort(keep["score"], kind="stable")]
 
 
 def mapCallback(data, oriMapCol, oriMapRow, mapResol, ctx=None):

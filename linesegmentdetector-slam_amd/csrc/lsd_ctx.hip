@@ -63,6 +63,8 @@ struct lsd_ctx {
     size_t mc_cap = 0, mc_hcap = 0;
     uint8_t *oc_in = nullptr, *oc_out = nullptr;        // occupancy-grid staging of the host entry point
     size_t oc_cap = 0;
+    uint8_t* mt_buf = nullptr;                          // staging of the host scan-to-map matching entry point
+    size_t mt_cap = 0;
     // options
     int stop_after = 0;
     bool trace = false;
@@ -274,7 +276,7 @@ void lsd_destroy(lsd_ctx* c) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
-                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out, c->oc_in, c->oc_out};
+                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -561,6 +563,63 @@ int lsd_occupancy_to_map(lsd_ctx* c, const int8_t* grid, int cols, int rows, uin
     const int st = lsd_enqueue_occupancy_to_map_device(c, reinterpret_cast<const int8_t*>(c->oc_in), wh, c->oc_out, c->stream);
     if (st != LSD_OK) return st;
     HIPCHK(c, hipMemcpy2DAsync(map_out, map_stride, c->oc_out, cols, cols, rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LSD_OK;
+}
+
+int lsd_enqueue_scan_to_map_match_device(lsd_ctx* c, const double* d_map_cache, int cols, int rows, const lsd_line* d_map_lines,
+                                         const lsd_line* d_scan_lines, const lsd_position* d_pts, int n_points,
+                                         lsd_position lidar, lsd_position last, const int* d_pairs, int n_pairs,
+                                         double z_occ_max_dis, double max_esti_dist, lsd_match_score* d_out, void* stream) {
+    if (!c || !d_map_cache || !d_map_lines || !d_scan_lines || !d_pairs || !d_out || cols <= 0 || rows <= 0 || n_pairs <= 0 ||
+        n_points < 0 || (n_points > 0 && !d_pts))
+        return LSD_ERR_INVALID;
+    if (n_pairs > (1 << 28)) return LSD_ERR_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    launch_match(d_map_cache, cols, rows, d_map_lines, d_scan_lines, reinterpret_cast<const double*>(d_pts), n_points, lidar.x,
+                 lidar.y, last.x, last.y, d_pairs, n_pairs, z_occ_max_dis, max_esti_dist, reinterpret_cast<double*>(d_out), s);
+    HIPCHK(c, hipGetLastError());
+    c->last_stream = s;
+    return LSD_OK;
+}
+
+int lsd_scan_to_map_match(lsd_ctx* c, const double* map_cache, int cols, int rows, const lsd_line* map_lines, int n_map,
+                          const lsd_line* scan_lines, int n_scan, const lsd_position* pts, int n_points, lsd_position lidar,
+                          lsd_position last, const int* pairs, int n_pairs, double z_occ_max_dis, double max_esti_dist,
+                          lsd_match_score* out) {
+    if (!c || !map_cache || !map_lines || !scan_lines || !pairs || !out || cols <= 0 || rows <= 0 || n_map <= 0 || n_scan <= 0 ||
+        n_pairs <= 0 || n_points < 0 || (n_points > 0 && !pts))
+        return LSD_ERR_INVALID;
+    for (int p = 0; p < n_pairs; p++)
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_map || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_scan) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t b_mc = (size_t)cols * rows * sizeof(double), b_ml = (size_t)n_map * sizeof(lsd_line), b_sl = (size_t)n_scan * sizeof(lsd_line);
+    const size_t b_pt = (size_t)(n_points > 0 ? n_points : 1) * sizeof(lsd_position), b_pr = (size_t)n_pairs * 2 * sizeof(int);
+    const size_t b_out = (size_t)n_pairs * 4 * sizeof(lsd_match_score);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t total = up(b_mc) + up(b_ml) + up(b_sl) + up(b_pt) + up(b_pr) + up(b_out);
+    if (total > c->mt_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->mt_buf, total));
+        c->mt_cap = total;
+    }
+    uint8_t* base = c->mt_buf;
+    double* d_mc = reinterpret_cast<double*>(base); base += up(b_mc);
+    lsd_line* d_ml = reinterpret_cast<lsd_line*>(base); base += up(b_ml);
+    lsd_line* d_sl = reinterpret_cast<lsd_line*>(base); base += up(b_sl);
+    lsd_position* d_pt = reinterpret_cast<lsd_position*>(base); base += up(b_pt);
+    int* d_pr = reinterpret_cast<int*>(base); base += up(b_pr);
+    lsd_match_score* d_out = reinterpret_cast<lsd_match_score*>(base);
+    HIPCHK(c, hipMemcpyAsync(d_mc, map_cache, b_mc, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_ml, map_lines, b_ml, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_sl, scan_lines, b_sl, hipMemcpyHostToDevice, c->stream));
+    if (n_points > 0) HIPCHK(c, hipMemcpyAsync(d_pt, pts, (size_t)n_points * sizeof(lsd_position), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pr, pairs, b_pr, hipMemcpyHostToDevice, c->stream));
+    const int st = lsd_enqueue_scan_to_map_match_device(c, d_mc, cols, rows, d_ml, d_sl, d_pt, n_points, lidar, last, d_pr, n_pairs,
+                                                        z_occ_max_dis, max_esti_dist, d_out, c->stream);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(out, d_out, b_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LSD_OK;
 }

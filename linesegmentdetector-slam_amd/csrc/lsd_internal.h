@@ -86,6 +86,9 @@ int region_waves();
 int region_blocks();   // block buffers per wave (glist and pend are sized x this)
 int region_blocks();
 void launch_calib(double* buf, size_t n, hipStream_t s);
+void launch_match(const double* map_cache, int cols, int rows, const lsd_line* map_lines, const lsd_line* scan_lines,
+                  const double* pts, int n_points, double lidx, double lidy, double lastx, double lasty, const int* pairs,
+                  int n_pairs, double zmax, double max_esti_dist, double* out, hipStream_t s);
 void launch_occ_to_map(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s);
 void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);

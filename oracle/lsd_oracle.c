@@ -757,3 +757,73 @@ void orc_debug_free(orc_debug *d)
     free(d->ord_v); free(d->ord_x); free(d->ord_y); free(d->seeds); free(d->recs);
     memset(d, 0, sizeof(*d));
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * myfa::thread_ScanToMapMatch batch (LSD/myFA.cpp:197-396).  PARITY UNPINNED (see lsd_oracle.h).
+ * ------------------------------------------------------------------------------------------------------------ */
+static double orc_pi(void) { return 4.0 * atan(1.0); }                     /* LSD/baseFunc.cpp:4 */
+static double orc_sind(double x) { return sin(x / 180.0 * orc_pi()); }     /* :6-8 */
+static double orc_cosd(double x) { return cos(x / 180.0 * orc_pi()); }     /* :10-12 */
+static double orc_atand(double x) { return atan(x) * 180.0 / orc_pi(); }   /* :14-16 */
+
+static double orc_line_direction(double staX, double staY, double endX, double endY)   /* myFA.cpp:272-305 */
+{
+    double angle;
+    if (staX == endX && staY != endY) angle = staY < endY ? 90 : -90;
+    else if (staX != endX && staY == endY) angle = staX < endX ? 0 : 180;
+    else angle = orc_atand((endY - staY) / (endX - staX));
+    if (angle < 0 && staX > endX) { angle += 180; return angle; }
+    if (angle > 0 && staX > endX) { angle -= 180; return angle; }
+    return angle;
+}
+
+int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
+                          const orc_line *map_lines, int n_map, const orc_line *scan_lines, int n_scan,
+                          const orc_position *pts, int n_points, orc_position lidar, orc_position last,
+                          const int *pairs, int n_pairs, double z_occ_max_dis, double max_esti_dist, orc_match_score *out)
+{
+    if (!map_cache || !map_lines || !scan_lines || !pairs || !out || (n_points > 0 && !pts)) return -1;
+    for (int p = 0; p < n_pairs; p++) {
+        const int im = pairs[2 * p], is = pairs[2 * p + 1];
+        if (im < 0 || im >= n_map || is < 0 || is >= n_scan) return -2;
+        const orc_line *ml = &map_lines[im], *sl = &scan_lines[is];
+        for (int i = 1; i <= 4; i++) {                                       /* :205-249 */
+            const int mrev = i >= 3, srev = (i == 2 || i == 4);
+            const double msx = mrev ? ml->x2 : ml->x1, msy = mrev ? ml->y2 : ml->y1;
+            const double mex = mrev ? ml->x1 : ml->x2, mey = mrev ? ml->y1 : ml->y2;
+            const double ssx = srev ? sl->x2 : sl->x1, ssy = srev ? sl->y2 : sl->y1;
+            const double sex = srev ? sl->x1 : sl->x2, sey = srev ? sl->y1 : sl->y2;
+            const double mapAng = orc_line_direction(msx, msy, mex, mey);    /* :252-258 */
+            const double scanAng = orc_line_direction(ssx, ssy, sex, sey);
+            double angDiff = mapAng - scanAng;                               /* :310 */
+            orc_match_score *o = &out[4 * p + i - 1];
+            /* rotateScanIm :323-326 */
+            const double rlx = (lidar.x - ssx) * orc_cosd(angDiff) - (lidar.y - ssy) * orc_sind(angDiff) + msx;
+            const double rly = (lidar.x - ssx) * orc_sind(angDiff) + (lidar.y - ssy) * orc_cosd(angDiff) + msy;
+            o->pos.x = rlx; o->pos.y = rly; o->pos.ang = 0; o->score = INFINITY;
+            if (!(sqrt(pow(rlx - last.x, 2) + pow(rly - last.y, 2)) < max_esti_dist || last.x == -1)) continue;   /* :330 */
+            const double cd = orc_cosd(angDiff), sd = orc_sind(angDiff);
+            double sumValidDist = 0, sumMaxDist = 0, numValidPoint = 0;      /* CalcScore :359-396 */
+            for (int c = 0; c < n_points; c++) {
+                const double ox = pts[c].x - ssx, oy = pts[c].y - ssy;       /* :317-320 */
+                const double rx = ox * cd - oy * sd + msx;                   /* :333-336 */
+                const double ry = ox * sd + oy * cd + msy;
+                const int x = cvt_int(round(rx)), y = cvt_int(round(ry));    /* :368-369 */
+                if (y >= 0 && y < rows && x >= 0 && x < cols) {
+                    numValidPoint += 1;
+                    const double v = map_cache[(size_t)y * cols + x];
+                    if (v >= z_occ_max_dis) sumMaxDist += 10;                /* :374-378 */
+                    else sumValidDist += v;
+                }
+            }
+            while (angDiff <= -180) angDiff += 360;                          /* :339-342 */
+            while (angDiff > 180) angDiff -= 360;
+            o->pos.ang = angDiff;
+            const double numAllPoint = n_points;
+            if (numValidPoint < 0.7 * numAllPoint) o->score = INFINITY;      /* :388-392 */
+            else o->score = (sumValidDist + sumMaxDist) / (numValidPoint) + 10 * (numAllPoint - numValidPoint) / numAllPoint;
+        }
+    }
+    return 0;
+}

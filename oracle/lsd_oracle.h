@@ -77,6 +77,19 @@ double orc_log_gamma(int x);
 void orc_free(void *p);
 void orc_debug_free(orc_debug *dbg);
 
+
+/* Restates one batch of myfa::thread_ScanToMapMatch (LSD/myFA.cpp:197-270): for every (map line, scan line) pair the
+ * four start/end matchings (:205-249), NormalizedLineDirection (:272-305), rotateScanIm (:307-357) and CalcScore
+ * (:359-396).  out[4 * pair + i - 1] = {rotated lidar pose, score}; score = INFINITY where rotateScanIm rejects the
+ * candidate (:327).  PARITY UNPINNED: the reference holds no input/output pair for this loop and cannot be built here;
+ * the GPU path is compared with this restatement only. */
+typedef struct { double x, y, ang; } orc_position;                 /* structPosition, LSD/baseFunc.h:46-50 */
+typedef struct { orc_position pos; double score; } orc_match_score;
+int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
+                          const orc_line *map_lines, int n_map, const orc_line *scan_lines, int n_scan,
+                          const orc_position *scan_im_points, int n_points, orc_position lidar_pose, orc_position last_pose,
+                          const int *pairs, int n_pairs, double z_occ_max_dis, double max_esti_dist, orc_match_score *out);
+
 #ifdef __cplusplus
 }
 #endif

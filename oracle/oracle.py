@@ -157,3 +157,30 @@ def occupancy_to_map(grid_i8):
     out[v == 255] = 0
     out[v == 0] = 255
     return out
+
+
+class _Pos(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("ang", C.c_double)]
+
+
+def scan_to_map_match(map_cache, map_lines, scan_lines, scan_im_points, lidar_pose, last_pose, pairs, z_occ=1.0,
+                      max_esti_dist=60.0, _lib=None):
+    """Oracle for one batch of myfa::thread_ScanToMapMatch (LSD/myFA.cpp:197-396).  PARITY UNPINNED (lsd_oracle.h).
+    Returns float64 [m, 4, 4]: (x, y, ang, score) per pair and matching."""
+    L = _lib or lib()
+    L.orc_scan_to_map_match.restype = C.c_int
+    L.orc_scan_to_map_match.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        _Pos, _Pos, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    mc = np.ascontiguousarray(map_cache, np.float64)
+    rows, cols = mc.shape
+    ml = np.ascontiguousarray(map_lines); sl = np.ascontiguousarray(scan_lines)
+    assert ml.dtype.itemsize == 80 and sl.dtype.itemsize == 80
+    pts = np.ascontiguousarray(scan_im_points).view(np.float64).reshape(-1, 3)
+    pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    out = np.zeros((len(pr), 4, 4), np.float64)
+    mk = lambda p: _Pos(float(p[0]), float(p[1]), float(p[2]) if len(p) > 2 else 0.0)
+    rc = L.orc_scan_to_map_match(mc.ctypes.data, cols, rows, ml.ctypes.data, len(ml), sl.ctypes.data, len(sl), pts.ctypes.data,
+                                 len(pts), mk(lidar_pose), mk(last_pose), pr.ctypes.data, len(pr), z_occ, max_esti_dist, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_scan_to_map_match failed: %d" % rc)
+    return out

@@ -193,3 +193,22 @@ def test_occupancy_to_map_exhaustive(oracle):
     want = np.ones(256, np.uint8); want[0] = 255; want[255] = 0           # 0 free -> 255, -1 unknown -> 0, 1..100 (and the rest) -> 1
     assert np.array_equal(got.ravel(), want)
     assert got[cells == -1].tolist() == [0] and got[cells == 100].tolist() == [1]
+
+
+def test_scan_to_map_match_restatement_finds_the_true_pose(maps, maps_meta, oracle, lsdmod):
+    """Sanity of the (unpinned) restatement of myfa::thread_ScanToMapMatch: on a synthetic frame cut out of a fixture map the
+    best-scoring candidate is the true pose."""
+    from matching_case import build_case
+    case = build_case(maps["aisle1"], maps_meta["aisle1"]["res"], oracle)
+    pairs = lsdmod.match_pairs(case["map_lines"], case["scan_lines"])
+    assert len(pairs) > 20
+    sc = oracle.scan_to_map_match(case["map_cache"], case["map_lines"], case["scan_lines"], case["pts"], case["lidar"],
+                                  (-1.0, -1.0, 0.0), pairs).reshape(-1, 4)
+    fin = sc[np.isfinite(sc[:, 3])]
+    best = fin[np.argmin(fin[:, 3])]
+    assert best[3] < 0.2                                                    # mean distance (m) of the scan cells to occupied map cells
+    assert abs(best[2] - case["theta"]) < 2.0 and np.hypot(*(best[:2] - case["lidar_map"])) < 3.0
+    # a last pose far away rejects every candidate (rotateScanIm :330)
+    far = oracle.scan_to_map_match(case["map_cache"], case["map_lines"], case["scan_lines"], case["pts"], case["lidar"],
+                                   (5000.0, 5000.0, 0.0), pairs)
+    assert np.isinf(far[..., 3]).all()

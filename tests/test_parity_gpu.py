@@ -452,3 +452,59 @@ def test_occupancy_device_and_map_callback(maps, maps_meta, known, lsdmod, ctx, 
     ref = oracle.lsd(m.copy())
     assert np.array_equal(mapValue, ref["map"]) if "map" in ref else True
     assert np.array_equal(mapCache, oracle.map_cache(m.copy(), res, 2.0))
+
+
+# ---- scan-to-map matching batch: floating point, tolerance stated below -------------------
+MATCH_TOL = 1e-9     # scores (metres) and poses (pixels / degrees): differences come only from 1-ulp libm differences in sin/cos/atan
+
+
+@pytest.mark.parametrize("name,theta,last", [("aisle1", 17.0, (-1.0, -1.0, 0.0)), ("aisle2", -63.0, (-1.0, -1.0, 0.0)),
+                                             ("aisle1", 17.0, (300.0, 260.0, 0.0)), ("aisle3", 90.0, (5000.0, 5000.0, 0.0))])
+def test_scan_to_map_match_parity(name, theta, last, maps, maps_meta, lsdmod, ctx, oracle):
+    from matching_case import build_case
+    case = build_case(maps[name], maps_meta[name]["res"], oracle, theta_deg=theta)
+    pairs = lsdmod.match_pairs(case["map_lines"], case["scan_lines"])
+    assert len(pairs) > 20
+    args = (case["map_cache"], case["map_lines"], case["scan_lines"], case["pts"], case["lidar"], last, pairs)
+    want = oracle.scan_to_map_match(*args).reshape(-1, 4)
+    got = ctx.scan_to_map_match(*args).reshape(-1)
+    g = np.stack([got["x"], got["y"], got["ang"], got["score"]], 1)
+    assert np.array_equal(np.isinf(g[:, 3]), np.isinf(want[:, 3]))            # the same candidates are rejected
+    fin = np.isfinite(want[:, 3])
+    if last[0] == 5000.0:
+        assert not fin.any()
+    else:
+        assert fin.sum() > 10
+    assert np.allclose(g[fin], want[fin], rtol=0, atol=MATCH_TOL)
+    assert np.allclose(g[~fin, :2], want[~fin, :2], rtol=0, atol=MATCH_TOL)   # the rotated lidar position is always reported
+    # the host mirror of FeatureAssociation's selection: score < 3, ascending
+    if last[0] == -1.0:
+        kept = lsdmod.ScanToMapMatch(case["map_cache"], case["map_lines"], case["scan_lines"], case["pts"], case["lidar"], last, ctx=ctx)
+        assert len(kept) == int((want[:, 3] < 3).sum()) and np.all(np.diff(kept["score"]) >= 0)
+        assert abs(kept["ang"][0] - theta) < 2.0 and np.hypot(kept["x"][0] - case["lidar_map"][0], kept["y"][0] - case["lidar_map"][1]) < 3.0
+
+
+def test_scan_to_map_match_device_resident(maps, maps_meta, lsdmod, ctx, oracle):
+    """mapCache produced on the device feeds the matching kernel directly (nothing but the scan goes over PCIe)."""
+    import ctypes, torch
+    from matching_case import build_case
+    m = maps["aisle1"]; res = maps_meta["aisle1"]["res"]
+    case = build_case(m, res, oracle)
+    pairs = lsdmod.match_pairs(case["map_lines"], case["scan_lines"])
+    rows, cols = m.shape
+    d_map = torch.from_numpy(m.copy()).cuda()
+    d_mc = torch.zeros((rows, cols), dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.enqueue_map_cache_device(d_map.data_ptr(), 1, cols, rows, res, 1.0, d_mc.data_ptr(), stream=s)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+    d_ml, d_sl, d_pts, d_pr = dev(case["map_lines"]), dev(case["scan_lines"]), dev(case["pts"]), dev(pairs)
+    d_out = torch.zeros((len(pairs) * 4, 4), dtype=torch.float64, device="cuda")
+    P = lsdmod.lsd_position
+    ctx._chk(ctx.L.lsd_enqueue_scan_to_map_match_device(ctx.h, d_mc.data_ptr(), cols, rows, d_ml.data_ptr(), d_sl.data_ptr(), d_pts.data_ptr(),
+                                                        len(case["pts"]), P(*case["lidar"]), P(-1.0, -1.0, 0.0), d_pr.data_ptr(), len(pairs),
+                                                        1.0, 60.0, d_out.data_ptr(), s))
+    torch.cuda.synchronize()
+    want = oracle.scan_to_map_match(case["map_cache"], case["map_lines"], case["scan_lines"], case["pts"], case["lidar"], (-1.0, -1.0, 0.0), pairs).reshape(-1, 4)
+    g = d_out.cpu().numpy()
+    fin = np.isfinite(want[:, 3])
+    assert np.array_equal(np.isinf(g[:, 3]), ~fin) and np.allclose(g[fin], want[fin], rtol=0, atol=MATCH_TOL)
