@@ -155,6 +155,10 @@ enum { LSD_STAGE_ALL = 0, LSD_STAGE_GAUSS = 1, LSD_STAGE_GRAD = 2, LSD_STAGE_SOR
 int lsd_set_stop_after(lsd_ctx *ctx, int stage);
 /* Enables the per-seed trace buffer (LSD_DBG_SEEDS); costs one record store per grown seed. */
 int lsd_set_trace(lsd_ctx *ctx, int on);
+/* Region stage variant: 4 wavefronts per image (two images per CU: batches that fill the device) or 8 (one image per CU,
+ * ~1.5x lower latency per image).  0 (default) picks 8 while the batch has at most one image per CU.  Results do not
+ * depend on the choice. */
+int lsd_set_region_waves(lsd_ctx *ctx, int waves);
 
 /* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
  *   GAUSS/MAG/DEG  h*w doubles      (GaussImage / magMap / degMap, myLSD.cpp:143-147)

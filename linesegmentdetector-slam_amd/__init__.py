@@ -98,6 +98,7 @@ def load_library(path=None):
     L.lsd_scaled_size.restype = None; L.lsd_scaled_size.argtypes = [i, i, dbl, C.POINTER(i), C.POINTER(i)]
     L.lsd_set_stop_after.restype = i; L.lsd_set_stop_after.argtypes = [vp, i]
     L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
+    L.lsd_set_region_waves.restype = i; L.lsd_set_region_waves.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
     L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsd_map_cache.restype = i; L.lsd_map_cache.argtypes = [vp, vp, i, i, sz, dbl, dbl, vp]
@@ -119,7 +120,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device"]
@@ -263,6 +264,10 @@ class Context:
 
     def set_trace(self, on):
         self._chk(self.L.lsd_set_trace(self.h, 1 if on else 0))
+
+    def set_region_waves(self, waves):
+        """0: automatic, 4 / 8: force the region-stage variant (results are identical)."""
+        self._chk(self.L.lsd_set_region_waves(self.h, waves))
 
     def fetch(self, image, what, shape_wh):
         """Returns the intermediate `what` (DBG_*) of image `image` of the last run as a numpy array."""

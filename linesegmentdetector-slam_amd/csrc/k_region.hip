@@ -27,7 +27,20 @@
 #include "lsd_internal.h"
 #include "devmath.h"
 
+// The file is compiled twice (Makefile): LSD_REGION_NW = 4 (two images per CU: the batch path, all 512 workgroups of the
+// bench batch resident at once) and LSD_REGION_NW = 8 (one image per CU, 8 speculative wavefronts per image: ~1.5x lower
+// latency per image, chosen when the batch leaves CUs idle anyway).  Everything lives in a per-variant namespace.
+#ifndef LSD_REGION_NW
+#define LSD_REGION_NW 4
+#endif
+#if LSD_REGION_NW == 8
+#define RVAR w8
+#else
+#define RVAR w4
+#endif
+
 namespace lsdhip {
+namespace RVAR {
 
 #ifndef LSD_REGION_NW
 #define LSD_REGION_NW 4
@@ -1620,14 +1633,20 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     }
 }
 
-void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
-    hipLaunchKernelGGL(k_region, dim3(n), dim3(64 * NW), 0, s, g, b, id_base, id_base16);
+}  // namespace RVAR
+
+#if LSD_REGION_NW == 8
+void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
+    hipLaunchKernelGGL(w8::k_region, dim3(n), dim3(64 * w8::NW), 0, s, g, b, id_base, id_base16);
 }
-
-int region_groups() { return NW * NG; }
-
-int region_waves() { return NW; }
-
-int region_blocks() { return NB; }
+// workspace is sized for the wider variant
+int region_groups() { return w8::NW * w8::NG; }
+int region_waves() { return w8::NW; }
+int region_blocks() { return w8::NB; }
+#else
+void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
+    hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base, id_base16);
+}
+#endif
 
 }  // namespace lsdhip

@@ -19,6 +19,8 @@ using namespace lsdhip;
 
 struct lsd_ctx {
     int device = 0;
+    int num_cus = 256;                 // compute units of the device
+    int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     hipStream_t stream = nullptr;      // the context's own stream
     hipStream_t last_stream = nullptr; // stream of the last enqueue
     std::string err;
@@ -262,6 +264,10 @@ int lsd_create(lsd_ctx** out, int device) {
     lsd_ctx* c = new (std::nothrow) lsd_ctx();
     if (!c) return LSD_ERR_NOMEM;
     c->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->num_cus = cus;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LSD_ERR_HIP; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return LSD_ERR_HIP; }
@@ -291,6 +297,12 @@ int lsd_set_stop_after(lsd_ctx* c, int stage) {
     c->stop_after = stage;
     return LSD_OK;
 }
+int lsd_set_region_waves(lsd_ctx* c, int waves) {
+    if (!c || (waves != 0 && waves != 4 && waves != 8)) return LSD_ERR_INVALID;
+    c->region_waves_mode = waves;
+    return LSD_OK;
+}
+
 int lsd_set_trace(lsd_ctx* c, int on) {
     if (!c) return LSD_ERR_INVALID;
     c->trace = on != 0;
@@ -356,7 +368,10 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             HIPCHK(c, hipMemsetAsync(c->gstamp, 0, c->cap_n * c->cap_npx * (size_t)region_groups() * sizeof(uint16_t), s));
             c->run16 = 1;
         }
-        launch_region(g, b, n, c->run_id << 20, c->run16 << 11, s);
+        // 8 wavefronts per image take a whole CU each: worth it while the batch leaves CUs idle (<= one image per CU)
+        const bool wide = c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= c->num_cus);
+        if (wide) launch_region_w8(g, b, n, c->run_id << 20, c->run16 << 11, s);
+        else launch_region_w4(g, b, n, c->run_id << 20, c->run16 << 11, s);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     if (c->stop_after == 0) launch_lines(g, b, n, s);

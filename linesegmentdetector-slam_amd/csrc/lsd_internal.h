@@ -80,11 +80,12 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
-void launch_region(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
-int region_groups();   // seed groups per image (NW * 8)
-int region_waves();
+// the region stage with 4 resp. 8 wavefronts per image (k_region.hip is compiled twice)
+void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
+void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
+int region_groups();   // seed groups per image (NW * 8) of the wider variant: what the workspace is sized for
+int region_waves();    // wavefronts per image of the wider variant
 int region_blocks();   // block buffers per wave (glist and pend are sized x this)
-int region_blocks();
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_match(const double* map_cache, int cols, int rows, const lsd_line* map_lines, const lsd_line* scan_lines,
                   const double* pts, int n_points, double lidx, double lidy, double lastx, double lasty, const int* pairs,

@@ -508,3 +508,23 @@ def test_scan_to_map_match_device_resident(maps, maps_meta, lsdmod, ctx, oracle)
     g = d_out.cpu().numpy()
     fin = np.isfinite(want[:, 3])
     assert np.array_equal(np.isinf(g[:, 3]), ~fin) and np.allclose(g[fin], want[fin], rtol=0, atol=MATCH_TOL)
+
+
+def test_region_stage_variants_agree(maps, lsdmod, ctx, oracle):
+    """The region stage exists with 4 and with 8 wavefronts per image (chosen by batch size): same lines, same usedMap."""
+    crop = lambda a: np.ascontiguousarray(a[:600, :1600])
+    imgs = np.stack([crop(maps["aisle1"]), crop(maps["aisle2"]), crop(maps["aisle3"])])
+    res = {}
+    try:
+        for waves in (4, 8):
+            ctx.set_region_waves(waves)
+            lines, offs, ims = ctx.run_batch(imgs.copy())
+            used = [(ctx.fetch(i, lsdmod.DBG_STATE, lsdmod.scaled_size(imgs.shape[2], imgs.shape[1])) & 3).astype(np.uint8) for i in range(3)]
+            res[waves] = (lines, offs, ims, used)
+    finally:
+        ctx.set_region_waves(0)
+    a, b = res[4], res[8]
+    assert np.array_equal(a[1], b[1]) and a[0].tobytes() == b[0].tobytes() and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    for i in range(3):
+        assert a[1][i + 1] - a[1][i] == len(oracle.lsd(imgs[i].copy())["lines"])
