@@ -91,6 +91,8 @@ void launch_match(const double* map_cache, int cols, int rows, const lsd_line* m
                   const double* pts, int n_points, double lidx, double lidy, double lastx, double lasty, const int* pairs,
                   int n_pairs, double zmax, double max_esti_dist, double* out, hipStream_t s);
 void launch_occ_to_map(const uint8_t* in, uint8_t* out, size_t n, hipStream_t s);
+void launch_mapcache_spread(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int* ctl,
+                            int* cnt, int n, int G, int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);

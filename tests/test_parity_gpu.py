@@ -528,3 +528,24 @@ def test_region_stage_variants_agree(maps, lsdmod, ctx, oracle):
     assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
     for i in range(3):
         assert a[1][i + 1] - a[1][i] == len(oracle.lsd(imgs[i].copy())["lines"])
+
+
+def test_map_cache_many_small_maps_one_workgroup_each(lsdmod, ctx, oracle):
+    """More than 64 maps take the one-workgroup-per-map kernel (fewer take the kernel-per-level one): same answers."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, rows, cols = 70, 96, 160
+    batch = np.zeros((n, rows, cols), np.uint8)
+    batch[rng.random(batch.shape) < 0.01] = 1
+    batch[rng.random(batch.shape) < 0.2] = 255
+    d = torch.from_numpy(batch).cuda()
+    out = torch.zeros(batch.shape, dtype=torch.float64, device="cuda")
+    ctx.enqueue_map_cache_device(d.data_ptr(), n, cols, rows, 0.05, 1.0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in (0, 1, 35, 69):
+        assert np.array_equal(got[i], oracle.map_cache(batch[i].copy(), 0.05))
+    few = torch.zeros((5, rows, cols), dtype=torch.float64, device="cuda")
+    ctx.enqueue_map_cache_device(d.data_ptr(), 5, cols, rows, 0.05, 1.0, few.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(few.cpu().numpy(), got[:5])
