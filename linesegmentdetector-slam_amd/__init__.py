@@ -298,8 +298,9 @@ class Context:
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                              "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
                              "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "_r23",
-                             "pt_pick", "pt_reads", "pt_classify", "pt_chain", "pt_commit", "pt_worklist", "all_batches", "_r31"),
+                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "resweep_batches",
+                             "cycles_group", "cycles_eval", "handed_regions", "handed_px", "cycles_idle", "cycles_select", "cycles_handed",
+                             "filter_skips"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)

@@ -98,7 +98,7 @@ struct RCtx {
 
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_SPILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
-       ST_WAIT, ST_R23, ST_PT0, ST_PT1, ST_PT2, ST_PT3, ST_PT4, ST_PT5, ST_ALLBATCHES, ST_R31, ST_COUNT };
+       ST_WAIT, ST_RESWEEP, ST_TGROUP, ST_TEVAL, ST_NHANDED, ST_PXHANDED, ST_TIDLE, ST_TSELECT, ST_THANDED, ST_SKIPPED, ST_COUNT };
 #define STAT(i, v) do { if (c.lane == 0) c.stat[i] += (unsigned long long)(v); } while (0)
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -223,11 +223,6 @@ __device__ __forceinline__ void invalidate_tiles(RCtx& c) {
 // Sweeps after the first revisit only entries that still had a non-member, non-banned neighbour
 // (membership and bans only grow during one call, so the others cannot accept anything).
 // ---------------------------------------------------------------------------------------------
-#ifdef LSD_PROFILE_GROW
-#define PT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT(ST_PT0 + (i), t_ - tp); tp = t_; } while (0)
-#else
-#define PT(i) do {} while (0)
-#endif
 
 constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
 
@@ -286,10 +281,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         int i = (sweep == 1 || !filter) ? 0 : n_start;       // contiguous cursor
         bool in_wl = (sweep > 1) && filter;
         while (true) {
-#ifdef LSD_PROFILE_GROW
-            long long tp = (long long)__builtin_amdgcn_s_memtime();
-            STAT(ST_ALLBATCHES, 1);
-#endif
             // ---- pick up to 8 entries ----
             int cnt, eidx;
             if (in_wl) {
@@ -324,7 +315,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                             nxt_cnt += nskip;
                         }
                         wi += nskip;
-                        STAT(ST_R31, nskip);
+                        STAT(ST_SKIPPED, nskip);
                         continue;
                     }
                     // the run of consecutive entries to test (no skipped entry in between: its check would be stale after an accept)
@@ -351,7 +342,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     ensure_tiles(c, inb, nx, ny);
                 }
             }
-            PT(0);
             const int q = ny * w + nx;
             // all per-pixel reads of the batch are issued together (cell is in range even for !inb lanes)
             const uint32_t word_r = c.t_st[cell];
@@ -361,7 +351,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
             const unsigned long long candm = __ballot(cand);
             unsigned long long acc = 0;                      // accepted lanes (one per accepted pixel)
             unsigned long long gone = 0;                     // every lane whose pixel became a member in this batch
-            PT(1);
             if (candm) {
                 // first occurrence of every candidate pixel: a lane is a repeat iff an EARLIER entry of the batch
                 // has the pixel in its 3x3 neighbourhood (that entry's lane for it comes first in reference order)
@@ -403,8 +392,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                 const unsigned long long A = __ballot(cand && amb);               // every occurrence, resolved in order
                 unsigned long long todo = P | A;
                 STAT(ST_BATCHES, 1);
-                if (sweep > 1) STAT(ST_R23, 1);
-                PT(2);
+                if (sweep > 1) STAT(ST_RESWEEP, 1);
                 while (todo) {
                     const int l = __builtin_ctzll(todo);
                     todo &= todo - 1ull;
@@ -437,7 +425,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                         if (!((P >> l) & 1ull)) gone |= __ballot(cand && q == __builtin_amdgcn_readlane(q, l));
                     }
                 }
-                PT(3);
                 if (acc) {
                     const bool mine = (acc >> lane) & 1ull;
                     if (mine) {
@@ -449,7 +436,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     c.dirty = true;
                     flt_valid = false;                       // the region angle moved
                 }
-                PT(4);
                 // entries that still have a growable non-member neighbour go to the next sweep's worklist
                 const unsigned long long left = candm & ~gone & ~__ballot(cand && pc);
                 if (filter && left) {
@@ -472,7 +458,6 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     }
                 }
             }
-            PT(5);
             if (in_wl) wi += cnt; else i += cnt;
         }
         uint16_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
@@ -1238,27 +1223,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
                     break;
                 }
-#ifdef LSD_VERIFY_GROW8
-                if (now != snap) {                         // not flagged as a conflict: verify by growing again at the cursor
-                    const uint32_t ppv = ord[seedidx[f]];
-                    if ((c.state[ppv] & 3u) == 0u && (rg.numo[f & (RW - 1)] & 3) == 0) {
-                        const int vx = (int)(ppv % (uint32_t)w), vy = (int)(ppv / (uint32_t)w);
-                        int vn; double vs, vc;
-                        wg_fence(); invalidate_tiles(c);
-                        grow(c, vx, vy, c.deg[ppv], g.degThre, vn, vs, vc);
-                        if (vn != rg.num0[f & (RW - 1)]) {
-                                            if (lane == 0 && c.stat[ST_R31] == 0ull) {
-                                c.stat[ST_R31] = ((unsigned long long)(unsigned)f << 32) | ((unsigned)rg.num0[f & (RW - 1)] << 16) | (unsigned)vn;
-                                c.stat[ST_PT0] = ((unsigned long long)(unsigned)snap << 32) | (unsigned)now;
-                                c.stat[ST_PT1] = ((unsigned long long)(unsigned short)bx[0] << 48) | ((unsigned long long)(unsigned short)bx[1] << 32) | ((unsigned long long)(unsigned short)bx[2] << 16) | (unsigned long long)(unsigned short)bx[3];
-                                const short* r0 = s_ring[snap & (RING - 1)];
-                                c.stat[ST_PT2] = ((unsigned long long)(unsigned short)r0[0] << 48) | ((unsigned long long)(unsigned short)r0[1] << 32) | ((unsigned long long)(unsigned short)r0[2] << 16) | (unsigned long long)(unsigned short)r0[3];
-                                c.stat[ST_PT3] = ((unsigned long long)(unsigned)vx << 32) | (unsigned)vy;
-                            }
-                        }
-                    }
-                }
-#endif
                 bool used_now = false;
                 if (trace) used_now = (c.state[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
                 if (!used_now) {
@@ -1295,18 +1259,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NB * NG * 24;
     const unsigned long long ltm = (1ull << lane) - 1ull;
     long long tl = (long long)__builtin_amdgcn_s_memtime();
-#ifdef LSD_PROFILE_GROW
-#define LT(i) do { (void)tl; } while (0)
-#else
-#define LT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT(ST_PT0 + (i), t_ - tl); tl = t_; } while (0)
-#endif
+    // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
+#define LT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT((i), t_ - tl); tl = t_; } while (0)
     while (true) {
         // ---- choose the next job ----
         int k;
         bool spec, from_group = false, from_stash = false;
         int epoch_snap;
         int st_buf = 0, st_k0 = 0;                         // buffer / first seed of the block a stashed result belongs to
-        LT(5);
+        LT(ST_TSELECT);
         // retire blocks whose results are all handed over and committed
         while (q_cnt > 0 && ((pend32 >> (8 * q_head)) & 0xffu) == 0u && (q_cnt > 1 || blk_g >= NG)) {
             q_head = (q_head + 1) % NB; q_cnt--;
@@ -1391,7 +1352,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     grow8(c, gact, gsx, gsy, wave_glist + ((size_t)cur_buf * NG + grp) * b.gcap, my_gwl, my_gstamp,
                           (uint16_t)(id_base16 + gid_local), g_ring[wave], b.gcap, g.degThre, blk);
                 }
-                LT(0);
+                LT(ST_TGROUP);
                 continue;
             } else if (kp >= 0) {
                 // ---- nothing else to do: wait for the turn of the earliest stashed result ----
@@ -1410,7 +1371,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 advance();
                 if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
                 __builtin_amdgcn_s_sleep(8);               // nothing left to hand out, or the run-ahead window is full
-                LT(4);
+                LT(ST_TIDLE);
                 continue;
             }
         }
@@ -1466,7 +1427,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     const long long tg0 = (long long)__builtin_amdgcn_s_memtime();
                     grow(c, sx, sy, seedDeg, tol, num, gs, gc);                       // :225 / :857
                     cur_is_group = false;
-                    if (pass == 0) { STAT(ST_ALLBATCHES, (long long)__builtin_amdgcn_s_memtime() - tg0); STAT(ST_PT2, 1); STAT(ST_PT3, num); }
+                    if (pass == 0) { STAT(ST_THANDED, (long long)__builtin_amdgcn_s_memtime() - tg0); STAT(ST_NHANDED, 1); STAT(ST_PXHANDED, num); }
 
                 }
                 if (pass == 0) {
@@ -1494,7 +1455,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         }
 
         // ---- hand the result over ----
-        LT(1);
+        LT(ST_TEVAL);
         if (spec) {
             if (skip) {
                 if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);

@@ -8,4 +8,4 @@ for i in ids:
     img = bench.make_image(maps, i, 2048)
     for rep in range(2): ctx.run(img.copy(), want_lineim=False)
     st = ctx.fetch(0, lsd.DBG_STATS, lsd.scaled_size(2048, 2048))
-    print(i, ctx.timings()["region"], {k: (round(v / 1e6, 1) if k.startswith(("cycles", "pt_")) else v) for k, v in st.items() if not k.startswith(("_", "pt_"))})
+    print(i, ctx.timings()["region"], {k: (round(v / 1e6, 1) if k.startswith("cycles") else v) for k, v in st.items()})
