@@ -198,7 +198,9 @@ def main():
                                if n == 512 and size == 2048 and ("k_" + k) in traffic_all and kt[k] > 0},
             "roofline": {"kernel": "k_gradient", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms},
+                         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms,
+                         "note": "north_star prices the gradient pass; k_region takes 97% of the step but is a serial latency chain "
+                                 "(about 2% of HBM peak, no MFMA work): DESIGN.md section 4, kernel_hbm_GBs below"},
         }
         if world == 1 and not a.no_cpu_baseline:
             # extras outside the timed region: single-image latency, and the device-copy ceiling of this box
