@@ -52,6 +52,14 @@ def build(asan=False):
     return os.path.join(_HERE, target)
 
 
+def lib_cr():
+    """The diagnostic variant with correctly rounded sin/cos/atan2 (oracle/cr_shim.cpp); built on demand."""
+    p = os.path.join(_HERE, "liblsd_oracle_cr.so")
+    if not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(os.path.join(_HERE, "lsd_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "liblsd_oracle_cr.so"], check=True, capture_output=True)
+    return lib(p)
+
+
 def lib(path=None):
     global _LIB
     if _LIB is not None and path is None:
