@@ -313,6 +313,37 @@ def test_bench_batch_sample_matches_oracle(maps, lsdmod, ctx, oracle):
         assert np.array_equal(ims[j], ref["lineIm"]), i
 
 
+def test_whole_bench_batch_matches_oracle(maps, lsdmod, ctx, oracle):
+    """BASELINE.json's full configuration -- the 512 x 2048x2048 batch bench.py times -- through the device entry point in ONE
+    launch sequence (the 4-wavefront region stage, every workgroup of the GPU speculating at once): every image's line count,
+    lineIm and line records against the oracle.  (~20 s, most of it the oracle.)"""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, size = 512, 2048
+    host = bench.make_batch(maps, n, size)
+    d = torch.from_numpy(host).cuda()
+    d_lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda")
+    d_counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_ims = torch.zeros((n, size, size), dtype=torch.uint8, device="cuda")
+    ctx.enqueue_device(d.data_ptr(), n, size, size, d_lines.data_ptr(), 1024, d_counts.data_ptr(), d_line_ims=d_ims.data_ptr(),
+                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cnt = d_counts.cpu().numpy()
+    rec = d_lines.cpu().numpy().view(np.uint8).reshape(n, 1024, 80)
+    assert cnt.max() <= 1024
+    total = 0
+    for i in range(n):
+        ref = oracle.lsd(host[i].copy())
+        assert cnt[i] == len(ref["lines"]), i
+        assert np.array_equal(d_ims[i].cpu().numpy(), ref["lineIm"]), i
+        assert_lines_close(rec[i, :cnt[i]].copy().view(lsdmod.LINE_DTYPE).reshape(-1), ref["lines"])
+        total += int(cnt[i])
+    assert total == 138815                                                     # lines_per_step of the bench line
+    del d, d_lines, d_ims
+    torch.cuda.empty_cache()
+
+
 def test_cpp_adapter_runs(maps, tmp_path):
     """The C++ host side (include/myLSD.h) end to end: same line count as the recorded reference answer."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
