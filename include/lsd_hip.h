@@ -89,7 +89,7 @@ int lsd_run_batch(lsd_ctx *ctx, uint8_t *maps, int n, int cols, int rows, const 
  *   d_lines    n x max_lines lsd_line (image i's lines start at d_lines + i*max_lines)
  *   d_counts   n int32 line counts (a count > max_lines means that image overflowed: LSD_ERR_CAPACITY
  *              is reported by lsd_batch_status, the first max_lines lines are valid)
- *   stream     hipStream_t on which to enqueue (NULL = the context's stream).  Asynchronous:
+ *   stream     hipStream_t on which to enqueue (NULL = the default stream, as everywhere in HIP).  Asynchronous:
  *              returns after enqueueing; workspace is (re)allocated before the first launch only
  *              when (n, cols, rows) grew. */
 #define LSD_FLAG_WRITEBACK_MAP 1u

@@ -38,6 +38,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
 }
 
 // The level loop of one workgroup on one map, from frontier `cur` (n nodes) at `level` until the flood dies out.
+// claim words are decided by atomics performed in L2: read them back from there, not from a line the CU's L1 may still hold
+__device__ __forceinline__ unsigned long long ld_claim(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void mc_run_levels(unsigned long long* cl, double* mc, uint32_t* cur, uint32_t* nxt, int n,
                                               unsigned long long level0, int W, int H, double res, int cell_radius, int* wsum) {
     const int tid = threadIdx.x;
@@ -77,10 +82,10 @@ __device__ __forceinline__ void mc_run_levels(unsigned long long* cl, double* mc
                 if (distance <= cell_radius) {
                     val = distance * res;                                        // :54
                     const unsigned long long key = (level << 40) | ((unsigned long long)i << 2);
-                    if (ci >= 1 && cl[c - W] == (key | 0ull)) won |= 1;
-                    if (cj >= 1 && cl[c - 1] == (key | 1ull)) won |= 2;
-                    if (ci < H - 1 && cl[c + W] == (key | 2ull)) won |= 4;
-                    if (cj < W - 1 && cl[c + 1] == (key | 3ull)) won |= 8;
+                    if (ci >= 1 && ld_claim(&cl[c - W]) == (key | 0ull)) won |= 1;
+                    if (cj >= 1 && ld_claim(&cl[c - 1]) == (key | 1ull)) won |= 2;
+                    if (ci < H - 1 && ld_claim(&cl[c + W]) == (key | 2ull)) won |= 4;
+                    if (cj < W - 1 && ld_claim(&cl[c + 1]) == (key | 3ull)) won |= 8;
                 }
             }
             int tot;

@@ -329,7 +329,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     int st = make_geom(p, cols, rows, &g);
     if (st != LSD_OK) return st;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
     st = ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)cols * rows, max_lines, c->trace);
     if (st != LSD_OK) return st;
     st = ensure_tables(c, p, g, s);
@@ -524,7 +524,7 @@ int lsd_enqueue_map_cache_device(lsd_ctx* c, const uint8_t* d_maps, int n, int c
     if (!c || !d_maps || !d_out || n <= 0 || cols <= 0 || rows <= 0 || !(res > 0) || !(z_occ_max_dis >= 0)) return LSD_ERR_INVALID;
     if ((long long)cols * rows >= (1ll << 31)) return LSD_ERR_UNSUPPORTED;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
     const size_t need = (size_t)n * cols * rows;
     if (need > c->mc_cap) {
         HIPCHK(c, hipDeviceSynchronize());
@@ -572,7 +572,7 @@ int lsd_enqueue_occupancy_to_map_device(lsd_ctx* c, const int8_t* d_grid, size_t
     if (!c || !d_grid || !d_map || n_cells == 0) return LSD_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(d_grid) | reinterpret_cast<uintptr_t>(d_map)) & 15u) return LSD_ERR_INVALID;   // 16-byte accesses
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
     launch_occ_to_map(reinterpret_cast<const uint8_t*>(d_grid), d_map, n_cells, s);
     HIPCHK(c, hipGetLastError());
     c->last_stream = s;
@@ -605,7 +605,7 @@ int lsd_enqueue_scan_to_map_match_device(lsd_ctx* c, const double* d_map_cache, 
         return LSD_ERR_INVALID;
     if (n_pairs > (1 << 28)) return LSD_ERR_UNSUPPORTED;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
     launch_match(d_map_cache, cols, rows, d_map_lines, d_scan_lines, reinterpret_cast<const double*>(d_pts), n_points, lidar.x,
                  lidar.y, last.x, last.y, d_pairs, n_pairs, z_occ_max_dis, max_esti_dist, reinterpret_cast<double*>(d_out), s);
     HIPCHK(c, hipGetLastError());
