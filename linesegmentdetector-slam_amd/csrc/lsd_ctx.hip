@@ -25,7 +25,7 @@ struct lsd_ctx {
     hipStream_t last_stream = nullptr; // stream of the last enqueue
     std::string err;
     // workspace capacity
-    size_t cap_n = 0, cap_npx = 0, cap_wh = 0;
+    size_t cap_n = 0, cap_npx = 0, cap_wh = 0, cap_ws = 0;   // images, scaled pixels per image, input pixels per image, wave slots
     int cap_max_lines = 0;
     bool cap_trace = false;
     // workspace
@@ -185,31 +185,38 @@ static hipError_t re_alloc(T** p, size_t count) {
     return hipMalloc((void**)p, count * sizeof(T));
 }
 
+// wavefronts per image of the region-stage build a batch of n images runs on (see launch below)
+static int waves_for(const lsd_ctx* c, int n) {
+    if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= c->num_cus)) return 8;
+    return 4;
+}
+
 static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
-    const bool grow_main = n > c->cap_n || npx > c->cap_npx;
+    const size_t need_ws = n * (size_t)waves_for(c, (int)n);       // per-wave arrays: wave slots of the whole batch
+    const bool grow_main = n > c->cap_n || npx > c->cap_npx || need_ws > c->cap_ws;
     if (grow_main) {
         const size_t nn = n > c->cap_n ? n : c->cap_n, pp = npx > c->cap_npx ? npx : c->cap_npx;
+        const size_t ws = need_ws > c->cap_ws ? need_ws : c->cap_ws;
         HIPCHK(c, hipDeviceSynchronize());
         const size_t tot = nn * pp;
         HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
         HIPCHK(c, re_alloc(&c->sn, tot)); HIPCHK(c, re_alloc(&c->cs, tot));
         HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
-        const size_t nwv = (size_t)region_waves();
-        HIPCHK(c, re_alloc(&c->spill, tot * nwv)); HIPCHK(c, re_alloc(&c->gcopy, tot * nwv)); HIPCHK(c, re_alloc(&c->wmeta, nn * nwv * (size_t)c->mcap * 2));
-        HIPCHK(c, re_alloc(&c->stamps, tot * nwv)); HIPCHK(c, re_alloc(&c->seedidx, tot));
-        HIPCHK(c, hipMemset(c->stamps, 0, tot * nwv * sizeof(uint32_t)));
+        HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap * 2));
+        HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot));
+        HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
         c->run_id = 0;
-        const size_t ngr = (size_t)region_groups();
-        HIPCHK(c, re_alloc(&c->glist, nn * ngr * (size_t)region_blocks() * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, nn * ngr * 2 * (size_t)c->gcap));
-        HIPCHK(c, re_alloc(&c->gstamp, tot * ngr));
-        HIPCHK(c, re_alloc(&c->pend, nn * ngr * (size_t)region_blocks() * 24));
-        HIPCHK(c, hipMemset(c->gstamp, 0, tot * ngr * sizeof(uint16_t)));
+        const size_t gs = ws * (size_t)(region_groups() / region_waves());      // group slots: 8 per wave slot
+        HIPCHK(c, re_alloc(&c->glist, gs * (size_t)region_blocks() * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, gs * 2 * (size_t)c->gcap));
+        HIPCHK(c, re_alloc(&c->gstamp, gs * pp));
+        HIPCHK(c, re_alloc(&c->pend, gs * (size_t)region_blocks() * 24));
+        HIPCHK(c, hipMemset(c->gstamp, 0, gs * pp * sizeof(uint16_t)));
         c->run16 = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * 32));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
-        c->cap_n = nn; c->cap_npx = pp;
+        c->cap_n = nn; c->cap_npx = pp; c->cap_ws = ws;
     }
     if (max_lines > c->cap_max_lines) {
         HIPCHK(c, hipDeviceSynchronize());
@@ -362,16 +369,16 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
         if (++c->run_id >= 1023u) {
-            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_n * c->cap_npx * (size_t)region_waves() * sizeof(uint32_t), s));
+            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * c->cap_npx * sizeof(uint32_t), s));
             c->run_id = 1;
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
         if (++c->run16 >= 32u) {
-            HIPCHK(c, hipMemsetAsync(c->gstamp, 0, c->cap_n * c->cap_npx * (size_t)region_groups() * sizeof(uint16_t), s));
+            HIPCHK(c, hipMemsetAsync(c->gstamp, 0, c->cap_ws * (size_t)(region_groups() / region_waves()) * c->cap_npx * sizeof(uint16_t), s));
             c->run16 = 1;
         }
         // 8 wavefronts per image take a whole CU each: worth it while the batch leaves CUs idle (<= one image per CU)
-        const bool wide = c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= c->num_cus);
+        const bool wide = waves_for(c, n) == 8;
         if (wide) launch_region_w8(g, b, n, c->run_id << 20, c->run16 << 11, s);
         else launch_region_w4(g, b, n, c->run_id << 20, c->run16 << 11, s);
     }
