@@ -54,47 +54,51 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     // thread first issues all its loads (up to 16 words in flight), then remaps (myLSD.cpp:135-142) and stores to LDS
     const int a0 = c0 - (((c0 % 4) + 4) % 4);
     {
+        // 32 word columns x 8 rows of threads: a thread keeps its word column and walks down the window 8 rows at a time, so the
+        // column work (bounds, reflection, "column 0 keeps raw values") is done once and nothing is divided
         const int DW = (c1 - a0 + 4) >> 2;                        // words per window row
-        const int ND = IH * DW;
         uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
         const int DWp = IWp >> 2;
-        for (int base = 0; base < ND; base += NT * 16) {
-            uint32_t v[16];
+        const int tx = tid & 31, ty = tid >> 5;
+        for (int cw = tx; cw < DW; cw += 32) {
+            const int gx0 = a0 + 4 * cw;
+            const bool fast_col = gx0 >= 0 && gx0 + 3 < W;        // the whole word lies inside the image
+            int gxr[4];
+            uint32_t colkeep = 0u;                                // bytes of source column 0: exempt from the remap (Q2)
             #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int d = base + tid + NT * j;
-                v[j] = 0u;
-                if (d < ND) {
-                    const int r = d / DW, cd = d - r * DW;
-                    const int gy = reflect_idx(r0 + r, H), gx0 = a0 + 4 * cd;
-                    const size_t off = (size_t)gy * W + gx0;
-                    if (gx0 >= 0 && gx0 + 3 < W && (off & 3) == 0) v[j] = *reinterpret_cast<const uint32_t*>(src + off);
-                    else {
-                        #pragma unroll
-                        for (int k2 = 0; k2 < 4; k2++) v[j] |= (uint32_t)src[(size_t)gy * W + reflect_idx(gx0 + k2, W)] << (8 * k2);
+            for (int k2 = 0; k2 < 4; k2++) {
+                gxr[k2] = reflect_idx(gx0 + k2, W);
+                if (gxr[k2] == 0) colkeep |= 0xffu << (8 * k2);
+            }
+            for (int rb = 0; rb < IH; rb += 8 * 16) {
+                uint32_t v[16];
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int r = rb + ty + 8 * j;
+                    v[j] = 0u;
+                    if (r < IH) {
+                        const int gy = reflect_idx(r0 + r, H);
+                        const size_t off = (size_t)gy * W + gx0;
+                        if (fast_col && (off & 3) == 0) v[j] = *reinterpret_cast<const uint32_t*>(src + off);
+                        else {
+                            const uint8_t* row = src + (size_t)gy * W;
+                            v[j] = (uint32_t)row[gxr[0]] | ((uint32_t)row[gxr[1]] << 8) | ((uint32_t)row[gxr[2]] << 16) | ((uint32_t)row[gxr[3]] << 24);
+                        }
                     }
                 }
-            }
-            #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int d = base + tid + NT * j;
-                if (d < ND) {
-                    const int r = d / DW, cd = d - r * DW;
-                    const int gy = reflect_idx(r0 + r, H), gx0 = a0 + 4 * cd;
-                    uint32_t x = v[j];
-                    // bytes == 1 -> 255, bytes == 255 -> 0; row 0 and column 0 keep their raw values (Q2)
-                    uint32_t t1 = x ^ 0x01010101u, t2 = ~x;       // zero bytes mark the two cases
-                    t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
-                    t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
-                    uint32_t m1 = (t1 >> 7) * 255u, m255 = (t2 >> 7) * 255u;
-                    uint32_t keep = 0u;                            // bytes exempt from the remap
-                    if (gy == 0) keep = 0xffffffffu;
-                    else {
-                        #pragma unroll
-                        for (int k2 = 0; k2 < 4; k2++) if (reflect_idx(gx0 + k2, W) == 0) keep |= 0xffu << (8 * k2);
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int r = rb + ty + 8 * j;
+                    if (r < IH) {
+                        const uint32_t x = v[j];
+                        // bytes == 1 -> 255, bytes == 255 -> 0 (myLSD.cpp:135-142); row 0 and column 0 keep their raw values (Q2)
+                        uint32_t t1 = x ^ 0x01010101u, t2 = ~x;   // zero bytes mark the two cases
+                        t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
+                        t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
+                        const uint32_t keep = reflect_idx(r0 + r, H) == 0 ? 0xffffffffu : colkeep;
+                        const uint32_t m1 = ((t1 >> 7) * 255u) & ~keep, m255 = ((t2 >> 7) * 255u) & ~keep;
+                        tile32[r * DWp + cw] = (x | m1) & ~m255;
                     }
-                    m1 &= ~keep; m255 &= ~keep;
-                    tile32[r * DWp + cd] = (x | m1) & ~m255;
                 }
             }
         }
@@ -109,14 +113,26 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
         const double* ker = taps + (gX % 3) * hSize;
         if (gX < w) {
             if (HS > 0) {
+                static_assert(HS <= 17, "the x-pass reads 5 words = 17 bytes at any byte offset");
                 double kr[HS > 0 ? HS : 1];
                 #pragma unroll
                 for (int i = 0; i < HS; i++) kr[i] = ker[i];
+                // the 17 window bytes start at any byte offset: read the 5 aligned words that hold them (conflict-free: the
+                // lanes of a row spread over ~27 banks and the odd row pitch separates the wave's two rows) and shift them into place
+                const uint32_t* trow = reinterpret_cast<const uint32_t*>(tile) + (cb >> 2);
+                const uint32_t sh = (uint32_t)(cb & 3);
+                const int DWp = IWp >> 2;
                 for (int r = tid / TW; r < IH; r += NT / TW) {
-                    const uint8_t* t = tile + r * IWp + cb;
+                    const uint32_t* t4 = trow + r * DWp;
+                    const uint32_t d0 = t4[0], d1 = t4[1], d2 = t4[2], d3 = t4[3], d4 = t4[4];
+                    uint32_t wv[5];
+                    wv[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); wv[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    wv[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); wv[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                    wv[4] = d4 >> (8u * sh);
                     double v = 0;
                     #pragma unroll
-                    for (int i = 0; i < HS; i++) v += (double)(int)t[i] * kr[i];
+                    for (int i = 0; i < HS; i++) v += (double)(int)((wv[i >> 2] >> (8 * (i & 3))) & 0xffu) * kr[i];
+
                     aux[r * TW + X] = v;
                 }
             } else {
@@ -142,6 +158,7 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
             if (HS > 0) {
                 #pragma unroll
                 for (int i = 0; i < HS; i++) v += aux[(rb + i) * TW + X] * ker[i];
+
             } else {
                 for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
             }
@@ -168,7 +185,8 @@ __global__ __launch_bounds__(256) void k_remap_inplace(uint8_t* __restrict__ img
 void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const int span = (int)floor((TW - 1) / g.sca) + 2;            // bound on centre(X0+31) - centre(X0) + 1
     const int IWmax = span + 2 * g.tapR + 1;
-    const int IWp = ((IWmax + 3) & ~3) + 4;                       // + the alignment slack of the word-wise staging
+    int IWp = ((IWmax + 3) & ~3) + 8;                             // + the alignment slack of the word-wise staging and of the x-pass's 5-word reads
+    if (((IWp >> 2) & 1) == 0) IWp += 4;                          // odd pitch in 32-bit words: consecutive rows start in different LDS banks
     const int IHmax = IWmax;
     const int hSize = 2 * g.tapR + 1;
     const size_t lds = (size_t)IHmax * TW * sizeof(double) + 3 * hSize * sizeof(double) + (size_t)IHmax * IWp;
