@@ -224,6 +224,9 @@ __device__ __forceinline__ void invalidate_tiles(RCtx& c) {
 // (membership and bans only grow during one call, so the others cannot accept anything).
 // ---------------------------------------------------------------------------------------------
 
+// an upper bound of 1 / v for v >= 0.9 (v_rcp_f32 is good to 1 ulp; the margins it feeds are themselves upper bounds)
+__device__ __forceinline__ float inv_ub(float v) { return __builtin_amdgcn_rcpf(v) * 1.000001f; }
+
 constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
 
 __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, double tol, int& out_num,
@@ -370,7 +373,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
                 }
                 double margin = Llb >= (tol_small ? 0.9f : 3.0f)
-                                    ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7
+                                    ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7
                                     : 1e30;
                 double raw = fabs(R - d);
                 double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;          // :540-542
@@ -380,7 +383,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                 if (!fresh && tol_small && __ballot(cand && amb)) {
                     // some candidate is too close to call with the drifted estimate: refresh it once and reclassify
                     R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
-                    margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+                    margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
                     raw = fabs(R - d);
                     dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
                     cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
@@ -418,7 +421,7 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                         cosS += rl(cd, l);                   // :545
                         sinS += rl(sd, l);                   // :546
                         // the estimate drifts by at most turn / |sum| per accepted pixel
-                        eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * (1.0f / Llb)) + 1e-9 : 1e30;
+                        eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * inv_ub(Llb)) + 1e-9 : 1e30;
                         Llb += cos_lb;
                         fresh = false;
                         acc |= 1ull << l;
@@ -589,7 +592,7 @@ __device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_
             const float sf = (float)sinS, cf = (float)cosS;
             Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
         }
-        double margin = Llb >= (tol_small ? 0.9f : 3.0f) ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+        double margin = Llb >= (tol_small ? 0.9f : 3.0f) ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
         double raw = fabs(R - d);
         double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;                   // :540-542
         bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
@@ -598,7 +601,7 @@ __device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_
         unsigned ab = grp_bits(__ballot(cand && amb), g);
         if (!fresh && tol_small && ab) {                     // too close to call with the drifted estimate: refresh once
             R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
-            margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * (1.0f / Llb)) + 1e-7 : 1e30;
+            margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
             raw = fabs(R - d);
             dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
             cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
@@ -634,7 +637,7 @@ __device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_
             if (take) {
                 cosS += cdl;                                 // :545
                 sinS += sdl;                                 // :546
-                eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * (1.0f / Llb)) + 1e-9 : 1e30;
+                eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * inv_ub(Llb)) + 1e-9 : 1e30;
                 Llb += cos_lb;
                 fresh = false;
                 accb |= bit;
