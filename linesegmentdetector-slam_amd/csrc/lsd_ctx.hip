@@ -87,7 +87,7 @@ struct lsd_ctx {
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
             (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
-            return LSD_ERR_HIP;                                                                   \
+            return e_ == hipErrorOutOfMemory ? LSD_ERR_NOMEM : LSD_ERR_HIP;                       \
         }                                                                                         \
     } while (0)
 
@@ -191,7 +191,7 @@ static int waves_for(const lsd_ctx* c, int n) {
     return 4;
 }
 
-static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
+static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
     const size_t need_ws = n * (size_t)waves_for(c, (int)n);       // per-wave arrays: wave slots of the whole batch
     const bool grow_main = n > c->cap_n || npx > c->cap_npx || need_ws > c->cap_ws;
     if (grow_main) {
@@ -233,6 +233,23 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
     return LSD_OK;
 }
 
+// A failed (re)allocation leaves some arrays freed and others at their old size: forget the whole workspace, so that the next
+// call starts from nothing instead of trusting stale capacities.
+static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
+    const int st = ensure_workspace_impl(c, n, npx, wh, max_lines, trace);
+    if (st != LSD_OK) {
+        (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
+        void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sn, (void**)&c->cs, (void**)&c->state,
+                         (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
+                         (void**)&c->seedidx, (void**)&c->glist, (void**)&c->gwl, (void**)&c->gstamp, (void**)&c->pend,
+                         (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->seeds,
+                         (void**)&c->recs, (void**)&c->recs_scaled};
+        for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+        c->cap_n = c->cap_npx = c->cap_ws = 0; c->cap_max_lines = 0; c->cap_trace = false;
+    }
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -248,7 +265,7 @@ const char* lsd_strerror(int st) {
         case LSD_ERR_HIP: return "HIP runtime error";
         case LSD_ERR_UNSUPPORTED: return "parameter outside the implemented range";
         case LSD_ERR_CAPACITY: return "line capacity exceeded";
-        case LSD_ERR_NOMEM: return "out of host memory";
+        case LSD_ERR_NOMEM: return "out of memory (host or device)";
         default: return "unknown status";
     }
 }

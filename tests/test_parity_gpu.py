@@ -603,3 +603,12 @@ def test_libm_tie_images_equal_the_correctly_rounded_restatement(name, kw, lsdmo
         assert np.array_equal(seeds[f], d["seeds"][f]), f
     assert np.array_equal(seeds["logNFA"], d["seeds"]["logNFA"])      # every NFA value, to the bit
     assert len(lines) != len(oracle.lsd(img.copy(), **kw)["lines"])   # ... and differs from the glibc-built one (the caveat)
+
+
+def test_out_of_memory_is_reported_not_fatal(lsdmod, ctx):
+    """A batch whose workspace cannot fit in HBM: LSD_ERR_NOMEM, and the context keeps working."""
+    with pytest.raises(lsdmod.LsdError) as e:
+        ctx.reserve(200000, 2048, 2048)                 # ~ 12 TB of workspace
+    assert e.value.status == lsdmod.LSD_ERR_NOMEM
+    lines, _ = ctx.run(np.zeros((64, 80), np.uint8))
+    assert len(lines) == 0
