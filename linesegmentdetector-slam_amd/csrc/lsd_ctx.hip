@@ -429,6 +429,7 @@ static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, b
         const size_t nn = n > c->hcap_n ? n : c->hcap_n, ww = wh > c->hcap_wh ? wh : c->hcap_wh;
         const int ml = max_lines > c->hcap_max_lines ? max_lines : c->hcap_max_lines;
         const bool li = lineim || c->hcap_lineim;
+        c->hcap_n = 0; c->hcap_wh = 0; c->hcap_max_lines = 0; c->hcap_lineim = false;   // (stay 0 if an allocation below fails)
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->h_in, nn * ww));
         HIPCHK(c, re_alloc(&c->h_lineim, li ? nn * ww : 0));
@@ -551,11 +552,13 @@ int lsd_enqueue_map_cache_device(lsd_ctx* c, const uint8_t* d_maps, int n, int c
     hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
     const size_t need = (size_t)n * cols * rows;
     if (need > c->mc_cap) {
+        c->mc_cap = 0;                                   // (stays 0 if an allocation below fails)
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->mc_claim, need)); HIPCHK(c, re_alloc(&c->mc_fa, need * 2)); HIPCHK(c, re_alloc(&c->mc_fb, need * 2));
         c->mc_cap = need;
     }
     if ((size_t)n > c->mc_ctl_n) {                                                     // frontier sizes + up to 64 chunk counts per map
+        c->mc_ctl_n = 0;
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->mc_ctl, (size_t)n * (2 + 64)));
         c->mc_ctl_n = (size_t)n;
@@ -580,6 +583,7 @@ int lsd_map_cache(lsd_ctx* c, const uint8_t* map, int cols, int rows, size_t str
     HIPCHK(c, hipSetDevice(c->device));
     const size_t wh = (size_t)cols * rows;
     if (wh > c->mc_hcap) {
+        c->mc_hcap = 0;
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->mc_in, wh)); HIPCHK(c, re_alloc(&c->mc_out, wh));
         c->mc_hcap = wh;
@@ -608,6 +612,7 @@ int lsd_occupancy_to_map(lsd_ctx* c, const int8_t* grid, int cols, int rows, uin
     HIPCHK(c, hipSetDevice(c->device));
     const size_t wh = (size_t)cols * rows;
     if (wh > c->oc_cap) {
+        c->oc_cap = 0;
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->oc_in, wh)); HIPCHK(c, re_alloc(&c->oc_out, wh));
         c->oc_cap = wh;
@@ -653,6 +658,7 @@ int lsd_scan_to_map_match(lsd_ctx* c, const double* map_cache, int cols, int row
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t total = up(b_mc) + up(b_ml) + up(b_sl) + up(b_pt) + up(b_pr) + up(b_out);
     if (total > c->mt_cap) {
+        c->mt_cap = 0;
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->mt_buf, total));
         c->mt_cap = total;
