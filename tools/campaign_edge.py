@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Developer tool: edge-shape campaign -- extreme aspect ratios, tiny images, maximum coordinates -- HIP path vs oracle."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+from oracle import oracle
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+oracle.build()
+ctx = lsd.Context(0)
+shapes = [(7, 7), (7, 65535), (65535, 7), (8, 30000), (30000, 9), (10, 10), (11, 4000), (4000, 13), (100, 100), (1, 1), (6, 6), (7, 6),
+          (3000, 3000), (64, 20000), (2, 50000)]
+bad = 0
+for k, (rows, cols) in enumerate(shapes):
+    rng = np.random.default_rng(900 + k)
+    m = np.zeros((rows, cols), np.uint8)
+    m[rng.random((rows, cols)) < 0.3] = 255
+    for _ in range(6):
+        y = int(rng.integers(0, rows)); x0 = int(rng.integers(0, max(1, cols - 2))); L = int(rng.integers(1, max(2, min(cols - x0, 500))))
+        m[y, x0:x0 + L] = 1
+        x = int(rng.integers(0, cols)); y0 = int(rng.integers(0, max(1, rows - 2))); L = int(rng.integers(1, max(2, min(rows - y0, 500))))
+        m[y0:y0 + L, x] = 1
+    w, h = lsd.scaled_size(cols, rows)
+    try:
+        lines, im = ctx.run(m.copy())
+    except lsd.LsdError as e:
+        ok_small = w < 2 or h < 2
+        print((rows, cols), "scaled", (w, h), "-> status", e.status, "(expected: scaled size below 2x2)" if ok_small else "UNEXPECTED")
+        bad += 0 if ok_small else 1
+        continue
+    ref = oracle.lsd(m.copy(), debug=True)
+    used = (ctx.fetch(0, lsd.DBG_STATE, (w, h)) & 3).astype(np.uint8)
+    ok = len(lines) == len(ref["lines"]) and np.array_equal(used, ref["dbg"]["used"]) and np.array_equal(im, ref["lineIm"])
+    print((rows, cols), "scaled", (w, h), "lines", len(lines), len(ref["lines"]), "OK" if ok else "MISMATCH", flush=True)
+    bad += 0 if ok else 1
+    mc = ctx.map_cache(m, 0.05)
+    if not np.array_equal(mc, oracle.map_cache(m.copy(), 0.05)):
+        print("   mapCache MISMATCH"); bad += 1
+print("edge campaign:", bad, "problems")
