@@ -11,6 +11,7 @@ lsd = importlib.import_module("linesegmentdetector-slam_amd")
 oracle.build()
 ctx = lsd.Context(0)
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+only = [int(x) for x in sys.argv[2:]]                      # optional: just these image numbers
 
 
 def synth(rng):
@@ -32,7 +33,7 @@ def synth(rng):
 
 bad = 0
 t0 = time.time()
-for i in range(n_img):
+for i in (only or range(n_img)):
     rng = np.random.default_rng(10_000 + i)
     img = synth(rng)
     kw = {}
@@ -49,5 +50,12 @@ for i in range(n_img):
         ok = all(np.abs(lines[f] - ref["lines"][f]).max() < 1e-6 for f in ("x1", "y1", "x2", "y2")) and np.array_equal(lines["orient"], ref["lines"]["orient"])
     if not ok:
         bad += 1
-        print("MISMATCH image", i, img.shape, kw, "lines", len(lines), "vs", len(ref["lines"]), "usedMap diff", int((used != d["used"]).sum()), flush=True)
+        # the diagnostic variant with correctly rounded sin/cos/atan2 (oracle/cr_shim.cpp): a libm tie if the HIP path equals it
+        rc = oracle.lsd(img.copy(), debug=True, _lib=oracle.lib_cr(), **kw)
+        eq = (len(lines) == len(rc["lines"]) and np.array_equal(used, rc["dbg"]["used"]) and np.array_equal(im, rc["lineIm"]) and
+              (len(lines) == 0 or all(np.abs(lines[f] - rc["lines"][f]).max() < 1e-6 for f in ("x1", "y1", "x2", "y2"))))
+        print("MISMATCH image", i, img.shape, kw, "lines", len(lines), "vs", len(ref["lines"]), "usedMap diff", int((used != d["used"]).sum()),
+              "| equals the correctly rounded restatement:", eq, flush=True)
+        if not eq:
+            np.save(os.path.join(ROOT, "gpurun_out", "campaign_bad_%d.npy" % i), img)
 print("campaign: %d images, %d mismatches, %.0f s" % (n_img, bad, time.time() - t0))
