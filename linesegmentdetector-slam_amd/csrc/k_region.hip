@@ -1116,8 +1116,8 @@ struct Ring {
     int state[RW];
     int snap[RW];
     short box[RW][4];
-    int num0[RW];
-    int numo[RW];        // (final_num << 2) | outcome
+    uint32_t lref[RW];   // list slot of the region ((wave * NB + buf) * NG + slot), ~0u: no lists kept (box check only)
+    uint32_t lcnt[RW];   // n1 | n2 << 16: sizes of the two lists in the slot (first grow, Refiner's regrow)
 };
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base, uint32_t id_base16) {
@@ -1164,6 +1164,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     double* recs = b.recs + img * (size_t)b.max_lines * 12;
     double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
     SeedRec* trace = b.seeds ? reinterpret_cast<SeedRec*>(b.seeds) + img * npx : nullptr;
+    int* rnum = b.rnum + img * (size_t)RW * 2;            // (num0, final_num << 2 | outcome) of published records: read by the seed trace only
 
     // potential seeds: sorted entries whose pixel is not below the gradient threshold (usedMap == 0 after K2)
     if (wave == 0) {
@@ -1205,6 +1206,28 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             s_ntrace = s_ntrace + 1;
         }
     };
+    // True if a pixel examined by a region (a member or one of its 8 neighbours) was banned by a line accepted in epoch
+    // >= snap: only then can the region's evaluation differ from what it would be now (it read usedMap only as
+    // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 above the usedMap bits.
+    auto examined_hit = [&](const uint32_t* lp, int cnt, int snap) -> bool {
+        bool hit = false;
+        for (int base = 0; base < cnt; base += 64) {
+            const int k2 = base + lane;
+            if (k2 < cnt) {
+                const uint32_t pkx = lp[k2];
+                const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+                #pragma unroll
+                for (int t9 = 0; t9 < 9; t9++) {
+                    const int xx = x + t9 % 3 - 1, yy = y + t9 / 3 - 1;
+                    if (xx >= 0 && yy >= 0 && xx < w && yy < h) {
+                        const uint32_t sw = c.state[(size_t)yy * w + xx];
+                        if ((sw & 3u) == 1u && (int)(sw >> 2) > snap) hit = true;
+                    }
+                }
+            }
+        }
+        return __ballot(hit) != 0ull;
+    };
     // Moves the commit cursor over finished records (one wave at a time).
     auto advance = [&]() {
         int got = 0;
@@ -1223,15 +1246,23 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 const int snap = rg.snap[f & (RW - 1)], now = lds_ld(&s_epoch);
                 const short* bx = rg.box[f & (RW - 1)];
                 if (now != snap && hit_since(snap, now, bx[0], bx[1], bx[2], bx[3])) {
-                    if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
-                    break;
+                    const uint32_t lr = rg.lref[f & (RW - 1)], lc = rg.lcnt[f & (RW - 1)];
+                    bool conflict = true;
+                    if (lr != ~0u) {                       // the lists are still in their slot: look at the pixels themselves
+                        wg_fence();
+                        conflict = examined_hit(b.glist + (img * (size_t)(NW * NB * NG) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
+                    }
+                    if (conflict) {
+                        if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
+                        break;
+                    }
                 }
                 bool used_now = false;
                 if (trace) used_now = (c.state[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
-                if (!used_now) {
-                    const int no = rg.numo[f & (RW - 1)];
-                    write_trace(f, rg.num0[f & (RW - 1)], no >> 2, no & 3, 0.0);
-                }
+                if (trace && !used_now) {
+                    const int no = rnum[(f & (RW - 1)) * 2 + 1];
+                    write_trace(f, rnum[(f & (RW - 1)) * 2], no >> 2, no & 3, 0.0);
+                } else if (!trace) write_trace(f, 0, 0, 0, 0.0);
                 if (lane == 0) { rg.state[f & (RW - 1)] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
@@ -1248,7 +1279,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     uint32_t gid_local = 0;                                // grows of this group in this run (16-bit stamp = id_base16 + it)
 
     int forced_k = -1;                                     // seed to (re)evaluate non-speculatively at the cursor
-    int blk_k0 = 0, blk_g = NG, blk_snap = 0;              // current block of 8 consecutive seeds, next group to hand over
+    int blk_k0 = -NG, blk_g = NG, blk_snap = 0;            // current block of 8 consecutive seeds, next group to hand over
     G8 blk;                                                // per-lane results of the block (group = lane>>3)
     blk.n = 0; blk.sinS = 0; blk.cosS = 0; blk.bx0 = blk.by0 = 0; blk.bx1 = blk.by1 = -1;
     bool blk_skip = true;
@@ -1319,7 +1350,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         rg.box[r][1] = (short)(qy0 - 1);
                         rg.box[r][2] = (short)(qx1 + 1);
                         rg.box[r][3] = (short)(qy1 + 1);
-                        rg.num0[r] = gn; rg.numo[r] = (gn << 2) | 0;
+                        rg.lref[r] = ~0u; rg.lcnt[r] = 0u;
+                        if (trace) { rnum[r * 2] = gn; rnum[r * 2 + 1] = (gn << 2) | 0; }
                         lds_st(&rg.state[r], R_LIGHT);
                     }
                     if (gq == NG - 1) advance();
@@ -1330,6 +1362,19 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 from_group = gn >= 0;                      // gn < 0: list overflow in group mode -> plain grow() below
             } else if (q_cnt < NB && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - NW * NG) {
                 // ---- fetch a block of 8 consecutive seeds and grow them together ----
+                if (NB == 1 && blk_k0 >= 0 && f < blk_k0 + NG) {
+                    // records of the previous block are still ahead of the cursor and its list slots are about to be reused:
+                    // withdraw their lists (under the cursor lock), their validation falls back to the bounding box
+                    while (true) {
+                        int got = 0;
+                        if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0 ? 1 : 0;
+                        if (__builtin_amdgcn_readfirstlane(got)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (lane < NG && blk_k0 + lane < nseeds) rg.lref[(blk_k0 + lane) & (RW - 1)] = ~0u;
+                    wg_fence();
+                    if (lane == 0) lds_st(&s_lock, 0);
+                }
                 int k0 = 0;
                 if (lane == 0) k0 = atomicAdd(&s_next, NG);
                 k0 = __builtin_amdgcn_readfirstlane(k0);
@@ -1389,6 +1434,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const uint32_t* m_src = nullptr;                   // stashed pixel list to mark at commit (else the wave's own list)
         int m_cnt = 0;
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1;              // box of everything the evaluation examined
+        int st_n1 = -1, st_n2 = 0;                         // stashed result: sizes of the lists kept in its slot (-1: none)
+        const uint32_t* st_list = nullptr;
         if (from_stash) {
             const int slot = k - st_k0;
             pend32 &= ~(1u << (8 * st_buf + slot));
@@ -1399,14 +1446,22 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             logNFA = rl(pv, 12);
             rec.pk = (int)rl(pv, 13); outcome = (int)rl(pv, 14); num0 = (int)rl(pv, 15); num = (int)rl(pv, 16); m_cnt = (int)rl(pv, 17);
             x0 = (int)rl(pv, 18); y0 = (int)rl(pv, 19); x1 = (int)rl(pv, 20); y1 = (int)rl(pv, 21);
-            m_src = wave_glist + ((size_t)st_buf * NG + slot) * b.gcap;
+            {
+                const long long pk3 = (long long)rl(pv, 22);
+                st_n1 = (int)(pk3 % 32768ll) - 1; st_n2 = (int)((pk3 / 32768ll) % 32768ll);
+                st_list = wave_glist + ((size_t)st_buf * NG + slot) * b.gcap;
+                m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
+            }
         } else {
         // ---- evaluate ----
         if (!from_group) { wg_fence(); }
         invalidate_tiles(c);
         skip = from_group ? false : (c.state[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
-        bool cur_is_group = false;                         // curMap == the group-mode list (no stamps of this wave)
+        // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
+        uint32_t* const gl0 = wave_glist + ((size_t)cur_buf * NG + (spec ? k - blk_k0 : 0)) * b.gcap;
+        int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
+        bool regrown = false;
         if (!skip) {
             // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
             // global tolerance (or takes the region grown in group mode), pass 1 (only when the rectangle is too
@@ -1424,13 +1479,17 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     for (int k2 = lane; k2 < num && k2 < LCAP; k2 += 64) c.lst[k2] = gl[k2];
                     for (int k2 = LCAP + lane; k2 < num; k2 += 64) c.spill[k2 - LCAP] = gl[k2];
                     c.gnum = num; c.has_copy = false;
-                    cur_is_group = true;
+                    n1 = num;
                     wg_fence();
                 } else {
                     const long long tg0 = (long long)__builtin_amdgcn_s_memtime();
                     grow(c, sx, sy, seedDeg, tol, num, gs, gc);                       // :225 / :857
-                    cur_is_group = false;
                     if (pass == 0) { STAT(ST_THANDED, (long long)__builtin_amdgcn_s_memtime() - tg0); STAT(ST_NHANDED, 1); STAT(ST_PXHANDED, num); }
+                    if (pass == 0 && spec && num <= b.gcap) {          // keep the first list for the validation at the cursor
+                        for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
+                        n1 = num;
+                    }
+                    if (pass == 1) regrown = true;
 
                 }
                 if (pass == 0) {
@@ -1479,23 +1538,42 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 }
             } else list_bbox(c, c.gnum, x0, y0, x1, y1);
             x0 -= 1; y0 -= 1; x1 += 1; y1 += 1;
+            bool precise = n1 >= 0;
+            int n2 = 0;
+            if (regrown) {                                 // keep Refiner's regrow (in grow order, before any reduction) behind the first list
+                if (precise && n1 + c.gnum <= b.gcap) {
+                    for (int k2 = lane; k2 < c.gnum; k2 += 64) gl0[n1 + k2] = c.has_copy ? c.gcopy[k2] : lget(c, k2);
+                    n2 = c.gnum;
+                } else precise = false;
+            }
+            const int slot = k - blk_k0;
             if (outcome <= 1) {                            // nothing to mark: publish and move on
                 if (lane == 0) {
                     const int r = k & (RW - 1);
                     rg.snap[r] = epoch_snap;
                     rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
-                    rg.num0[r] = num0; rg.numo[r] = (num << 2) | outcome;
+                    rg.lref[r] = precise ? (uint32_t)((wave * NB + cur_buf) * NG + slot) : ~0u;
+                    rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
+                    if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
                     lds_st(&rg.state[r], R_LIGHT);
                 }
                 advance();
                 continue;
             }
-            // marks to make: stash the result (the pixels to mark go to this seed's glist slot) and carry on with the block
-            const int slot = k - blk_k0;
-            uint32_t* gl = wave_glist + ((size_t)cur_buf * NG + slot) * b.gcap;
-            int mcnt = num;                                // a group-mode region that was kept as grown: glist[slot] is the list
-            if (!cur_is_group) {
-                if (c.gnum > b.gcap) {                     // does not fit the slot: evaluate again at the cursor
+            // marks to make: stash the result (record in pend[], the pixels to mark in the list slot) and carry on with the block
+            int m_off = 0, mcnt = num;                     // not regrown: the first list is exactly the region
+            if (!regrown) {
+                if (!precise) {                            // (larger than a list slot) evaluate again at the cursor
+                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
+                    STAT(ST_REDO, 1);
+                    advance();
+                    continue;
+                }
+            } else if (precise && !c.has_copy) { m_off = n1; mcnt = n2; }      // the regrow as it is
+            else {
+                m_off = precise ? n1 + n2 : 0;
+                if (m_off + c.gnum > b.gcap) { precise = false; m_off = 0; }
+                if (c.gnum > b.gcap) {
                     if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
                     STAT(ST_REDO, 1);
                     advance();
@@ -1513,7 +1591,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == c.cur_id;   // curMap == 1 only
                     }
                     const unsigned long long km = __ballot(keep);
-                    if (keep) gl[mcnt + __builtin_popcountll(km & ltm)] = pkx;
+                    if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
                     mcnt += __builtin_popcountll(km);
                 }
             }
@@ -1523,6 +1601,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 P[7] = rec.deg; P[8] = rec.dx; P[9] = rec.dy; P[10] = rec.p; P[11] = rec.prec; P[12] = logNFA;
                 P[13] = (double)rec.pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
                 P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
+                P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
             }
             wg_fence();
             pend32 |= 1u << (8 * cur_buf + slot);
@@ -1541,9 +1620,13 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
             const int now = lds_ld(&s_epoch);
             if (now != epoch_snap && hit_since(epoch_snap, now, x0, y0, x1, y1)) {
-                STAT(ST_REDO, 1);
-                forced_k = k;                              // evaluate again; everything earlier is committed now
-                continue;
+                bool conflict = true;
+                if (st_n1 >= 0) conflict = examined_hit(st_list, st_n1 + st_n2, epoch_snap);   // the pixels themselves
+                if (conflict) {
+                    STAT(ST_REDO, 1);
+                    forced_k = k;                          // evaluate again; everything earlier is committed now
+                    continue;
+                }
             }
         }
 
@@ -1567,7 +1650,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     double* rs = recs_scaled + (size_t)li * 4;
                     rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
                 }
-                mark_region(c, 1u, m_src, m_cnt, bx0, by0, bx1, by1);                              // :259-265
+                mark_region(c, 1u | ((uint32_t)(lds_ld(&s_epoch) + 1) << 2), m_src, m_cnt, bx0, by0, bx1, by1);   // :259-265 (+ the line's epoch)
                 wg_fence();                               // the marks must be visible before the epoch moves
                 if (lane == 0) {
                     const int ep = s_epoch;
@@ -1607,6 +1690,7 @@ void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, 
 int region_groups() { return w8::NW * w8::NG; }
 int region_waves() { return w8::NW; }
 int region_blocks() { return w8::NB; }
+int region_ring() { return w8::RW; }
 #else
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
     hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base, id_base16);

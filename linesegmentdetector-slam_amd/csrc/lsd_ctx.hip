@@ -38,6 +38,7 @@ struct lsd_ctx {
     uint16_t* gstamp = nullptr;
     double* pend = nullptr;
     float* wmeta = nullptr;
+    int* rnum = nullptr;
     int mcap = 16384;
     int gcap = 16384;
     uint16_t* ordv = nullptr;
@@ -213,7 +214,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, in
         HIPCHK(c, hipMemset(c->gstamp, 0, gs * pp * sizeof(uint16_t)));
         c->run16 = 0;
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * 32));
+        HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp; c->cap_ws = ws;
@@ -242,7 +243,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sn, (void**)&c->cs, (void**)&c->state,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
                          (void**)&c->seedidx, (void**)&c->glist, (void**)&c->gwl, (void**)&c->gstamp, (void**)&c->pend,
-                         (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->seeds,
+                         (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
         c->cap_n = c->cap_npx = c->cap_ws = 0; c->cap_max_lines = 0; c->cap_trace = false;
@@ -306,7 +307,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -364,7 +365,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
-    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap; b.pend = c->pend;
+    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;

@@ -47,6 +47,7 @@ struct Buffers {
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
     float* wmeta;          // n x NW x mcap x 2 : per list entry (reference angle, slack) of its last neighbourhood test
     int mcap;
+    int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
     // group-mode region growing (8 seeds per wavefront): per (image, wave, group) private storage
     uint32_t* glist;       // n x NW x NB x 8 x gcap : region lists (grow order) of the blocks in flight
@@ -86,6 +87,7 @@ void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, 
 int region_groups();   // seed groups per image (NW * 8) of the wider variant: what the workspace is sized for
 int region_waves();    // wavefronts per image of the wider variant
 int region_blocks();   // block buffers per wave (glist and pend are sized x this)
+int region_ring();     // commit-ring records per image (rnum is sized x this x 2)
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_match(const double* map_cache, int cols, int rows, const lsd_line* map_lines, const lsd_line* scan_lines,
                   const double* pts, int n_points, double lidx, double lidy, double lastx, double lasty, const int* pairs,
