@@ -512,8 +512,20 @@ struct G8 {                      // per-lane results (identical within a group)
 __device__ __forceinline__ unsigned grp_bits(unsigned long long m, int g) { return (unsigned)((m >> (8 * g)) & 0xffull); }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
 
-__device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_t* glist, uint32_t* gwl, uint16_t* gstamp,
-                                      uint16_t id, uint32_t* ring, int gcap, double tol, G8& out) {
+// (out of line on purpose: inlined into the seed loop its step loop spills to scratch, and a scratch reload per step is a memory
+//  round trip on the critical path; as a function it gets the register file to itself and saves the caller's registers once)
+struct G8Ctx {                   // what grow8 needs of RCtx, passed by value
+    int w, h, lane;
+    const double* deg;
+    const double* sn;
+    const double* cs;
+    const uint32_t* state;
+    unsigned long long* stat;
+};
+
+__device__ __noinline__ G8 grow8(G8Ctx c, bool act, int sx, int sy, uint32_t* glist, uint32_t* gwl, uint16_t* gstamp,
+                                 uint16_t id, uint32_t* ring, int gcap, double tol) {
+    G8 out;
     const int lane = c.lane, w = c.w, h = c.h;
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     const int g = lane >> 3, j = lane & 7, gbase = g * 8;
@@ -688,6 +700,7 @@ __device__ __forceinline__ void grow8(RCtx& c, bool act, int sx, int sy, uint32_
     out.sinS = sinS; out.cosS = cosS;
     out.bx0 = x0; out.by0 = y0; out.bx1 = x1; out.by1 = y1;
     STAT(ST_TGROW, (long long)__builtin_amdgcn_s_memtime() - t0);
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1397,8 +1410,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     blk.n = -1;
                 } else {
                     gid_local++;
-                    grow8(c, gact, gsx, gsy, wave_glist + ((size_t)cur_buf * NG + grp) * b.gcap, my_gwl, my_gstamp,
-                          (uint16_t)(id_base16 + gid_local), g_ring[wave], b.gcap, g.degThre, blk);
+                    G8Ctx gc;
+                    gc.w = w; gc.h = h; gc.lane = lane; gc.deg = c.deg; gc.sn = c.sn; gc.cs = c.cs; gc.state = c.state; gc.stat = c.stat;
+                    blk = grow8(gc, gact, gsx, gsy, wave_glist + ((size_t)cur_buf * NG + grp) * b.gcap, my_gwl, my_gstamp,
+                                (uint16_t)(id_base16 + gid_local), g_ring[wave], b.gcap, g.degThre);
                 }
                 LT(ST_TGROUP);
                 continue;
