@@ -495,10 +495,10 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
 // ---------------------------------------------------------------------------------------------
 constexpr int NG = 8;
 #ifndef LSD_G8_MIN_STEPS
-#define LSD_G8_MIN_STEPS 24
+#define LSD_G8_MIN_STEPS 48
 #endif
 #ifndef LSD_G8_MIN_ACTIVE
-#define LSD_G8_MIN_ACTIVE 3
+#define LSD_G8_MIN_ACTIVE 2
 #endif
 constexpr int G8_MIN_STEPS = LSD_G8_MIN_STEPS;    // group mode always runs this many steps ...
 constexpr int G8_MIN_ACTIVE = LSD_G8_MIN_ACTIVE;  // ... and goes on while at least this many of the 8 regions are still growing
