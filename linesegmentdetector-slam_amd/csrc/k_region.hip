@@ -55,6 +55,9 @@ constexpr int RING = 128;    // remembered bounding boxes of recently accepted l
 #ifndef LSD_REGION_NB
 #define LSD_REGION_NB 1
 #endif
+#if LSD_REGION_NB != 1
+#error "more than one block buffer per wave is not supported (the list-withdrawal at refetch assumes one; 2-4 buffers were measured slower and are untested since)"
+#endif
 constexpr int NB = LSD_REGION_NB;        // blocks of 8 seeds a wave may have in flight (evaluated, waiting for their turn to commit)
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
