@@ -628,11 +628,16 @@ __device__ __noinline__ G8 grow8(G8Ctx c, bool act, int sx, int sy, uint32_t* gl
         ab = grp_bits(am, g);
         unsigned accb = 0;
         // ---- the chain: neighbour jj of every group takes its turn (reference order inside a group) ----
+        // (only the neighbour positions some group has work at: the union over the groups, folded on the scalar unit)
+        unsigned long long fold = pm | am;
+        fold |= fold >> 32; fold |= fold >> 16; fold |= fold >> 8;
+        unsigned any8 = (unsigned)fold & 0xffu;
         #pragma unroll 1
-        for (int jj = 0; jj < 8; jj++) {
+        while (any8) {
+            const int jj = __builtin_ctz(any8);
+            any8 &= any8 - 1u;
             const unsigned bit = 1u << jj;
             const bool isp = (pb & bit) != 0u, isa = (ab & bit) != 0u;
-            if (!__ballot(isp || isa)) continue;
             bool take = isp;
             if (isa) {
                 const double dl = shfl_d(d, gbase + jj);
