@@ -501,10 +501,12 @@ constexpr int NG = 8;
 #define LSD_G8_MIN_STEPS 48
 #endif
 #ifndef LSD_G8_MIN_ACTIVE
-#define LSD_G8_MIN_ACTIVE 2
+#define LSD_G8_MIN_ACTIVE 1
 #endif
 constexpr int G8_MIN_STEPS = LSD_G8_MIN_STEPS;    // group mode always runs this many steps ...
 constexpr int G8_MIN_ACTIVE = LSD_G8_MIN_ACTIVE;  // ... and goes on while at least this many of the 8 regions are still growing
+                                                  // (1 = to the end: since the group step got cheaper than a wave-wide batch per pixel,
+                                                  //  only regions that outgrow their list slot are handed over)
 
 struct G8 {                      // per-lane results (identical within a group)
     int n;                       // region size; -1: list capacity exceeded (caller falls back to grow())
