@@ -9,17 +9,24 @@
 // usedMap left by all earlier ones.  What actually couples two seeds is small, though: a seed's whole
 // evaluation (grow, rectangle, refine, NFA) reads usedMap only through "is this pixel banned
 // (== 1)?", and only ACCEPTED lines ever set a pixel to 1 (rejected regions set 2, which stays
-// growable; small/failed regions set nothing).  So the NW wavefronts of a workgroup evaluate NW
-// consecutive seeds SPECULATIVELY and concurrently, and commit in seed order:
-//   * a wave takes the next seed (LDS counter), notes the accept epoch, drops its tile cache and
-//     evaluates the seed against the current usedMap with its private curMap stamps;
-//   * it then waits for its turn (commit cursor), re-checks that the seed pixel is still unused and
-//     that no line accepted since its snapshot touches the bounding box of what it examined; if one
-//     does, it simply re-evaluates the seed (now non-speculatively: everything earlier is committed);
-//   * commit = mark usedMap (1 or 2), append the rectangle, advance the cursor.
-// The committed sequence of decisions is therefore exactly the sequential one.
+// growable; small/failed regions set nothing).  So the wavefronts of a workgroup evaluate seeds
+// SPECULATIVELY ahead of a commit cursor and commit in seed order:
+//   * a wave takes a block of 8 consecutive seeds, notes the accept epoch, and grows the 8 regions together
+//     in group mode (grow8(): 8 lanes per region, one frontier entry per step, private lists / stamps in HBM);
+//   * it evaluates the grown regions one by one with all 64 lanes (rectangle, Refiner incl. its regrow with
+//     the wave-wide batched grow(), NFA); results that mark nothing are published in an LDS ring, results
+//     that mark usedMap are stashed (record + pixel list) and committed when the cursor reaches them;
+//   * at its turn a result is valid if its seed is still unused and no pixel it EXAMINED (a member of one of
+//     its grown lists or one of their 8 neighbours) was banned since its snapshot -- accepted pixels carry
+//     their line's epoch above the usedMap bits, the boxes of recently accepted lines are a first filter;
+//     an invalid result is evaluated again at the cursor, where everything earlier is committed;
+//   * commit = mark usedMap (1 + epoch, or 2), append the rectangle, advance the cursor.
+// The committed sequence of decisions is therefore exactly the sequential one (DESIGN.md section 4 has the
+// measurements behind every choice, and the variants that were tried and dropped).
 // Inside a wavefront the lanes cooperate where the order of evaluation can be kept:
-//   * region growing: 8 frontier pixels x 8 neighbours per batch, see grow();
+//   * region growing: 8 regions x 8 neighbours per step (grow8) or 8 frontier pixels x 8 neighbours of ONE
+//     region per batch (grow); angle sums in reference order, candidates classified against an estimate of
+//     the region angle with a rigorous margin, exact angle only when too close to call;
 //   * rectangle moments: products per lane, SERIAL accumulation in list order (bit-exact sums);
 //   * NFA pixel count: the rectangle's columns are flattened with a wave prefix sum and counted
 //     with ballot/popcount;
