@@ -35,12 +35,31 @@
 #include <opencv2/core.hpp>
 #endif
 
-/* structLinesInfo, LSD/baseFunc.h:33-44 (skipped when the reference's baseFunc.h was included first) */
+/* Shared types and defaults of LSD/baseFunc.h.  The reference's own LSD/myLSD.h:37 does `#include <baseFunc.h>`, and its
+ * callers include <myLSD.h> FIRST and <baseFunc.h> again afterwards (LSD/main_on_windows.cpp:5-8), so this header does the
+ * same whenever the reference's baseFunc.h is on the include path (its include guard, _BASEFUNC_, makes the later include a
+ * no-op).  Without the reference tree the few names this path needs are declared here under the SAME guard, so that a
+ * baseFunc.h that turns up later in the translation unit (e.g. through a quoted include) is skipped instead of colliding. */
+#if !defined(_BASEFUNC_) && defined(__has_include)
+#if __has_include(<baseFunc.h>)
+#include <baseFunc.h>
+#endif
+#endif
 #ifndef _BASEFUNC_
-typedef struct _structLinesInfo {
+#define _BASEFUNC_
+#define LSD_ADAPTER_OWN_BASEFUNC 1
+typedef struct _structMapParam { /* LSD/baseFunc.h:25-31 */
+    int oriMapCol, oriMapRow;
+    double mapResol, mapOriX, mapOriY;
+} structMapParam;
+typedef struct _structLinesInfo { /* LSD/baseFunc.h:33-44 */
     double k, b, dx, dy, x1, y1, x2, y2, len;
     int orient;
 } structLinesInfo;
+typedef struct _structPosition { /* LSD/baseFunc.h:46-50 */
+    double x, y, ang;
+} structPosition;
+static const double z_occ_max_dis = 1; /* LSD/baseFunc.h:60 */
 /* LSD defaults, LSD/baseFunc.h:64-68 */
 static const double lsd_sca = 0.3, lsd_sig = 0.6, lsd_angThre = 22.5, lsd_denThre = 0.7;
 static const int pseBin = 1024;
@@ -137,7 +156,7 @@ inline MatF64 make_f64(int rows, int cols) { return cv::Mat::zeros(rows, cols, C
 typedef lsd::Image<double> MatF64;
 inline MatF64 make_f64(int rows, int cols) { return MatF64::zeros(rows, cols); }
 #endif
-inline MatF64 createMapCache(Mat MapGray, double res, double z_occ_max_dis_ = 1.0) {
+inline MatF64 createMapCache(Mat MapGray, double res, double z_occ_max_dis_ = z_occ_max_dis) {
     lsd_ctx* c = context();
     MatF64 out = make_f64(MapGray.rows, MapGray.cols);
     const int st = lsd_map_cache(c, MapGray.template ptr<unsigned char>(0), MapGray.cols, MapGray.rows, (size_t)MapGray.step,

@@ -120,3 +120,125 @@ def test_cpp_adapter_compiles(built, tmp_path):
                     "-L", pkg, "-llsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+# A header with the include guard and the colliding names of the reference's LSD/baseFunc.h (:20-88): what a caller that
+# has the reference tree sees under that file name.  (Test double written here: the real one pulls in Eigen, absent in
+# this image; only the guard and the names matter for the collision.)
+_BASEFUNC_DOUBLE = '''
+#ifndef _BASEFUNC_
+#define _BASEFUNC_
+#define TEST_SAW_REFERENCE_BASEFUNC 1
+typedef struct _structMapParam { int oriMapCol; int oriMapRow; double mapResol; double mapOriX; double mapOriY; } structMapParam;
+typedef struct _structLinesInfo { double k; double b; double dx; double dy; double x1; double y1; double x2; double y2; double len; int orient; } structLinesInfo;
+typedef struct _structPosition { double x; double y; double ang; } structPosition;
+double sind(double x); double cosd(double x); double atand(double x);
+const double z_occ_max_dis = 1;
+const double lsd_sca = 0.3; const double lsd_sig = 0.6; const double lsd_angThre = 22.5; const double lsd_denThre = 0.7;
+const int pseBin = 1024;
+const int maxEstiDist = 60;
+#endif
+'''
+
+_CALLER = '''
+%s
+int main() {
+  structMapParam mp; mp.oriMapCol = 608;
+  structPosition pose; pose.x = 0;
+  mylsd::structLSD (*f)(mylsd::Mat, int, int, double, double, double, double, int) = &mylsd::myLineSegmentDetector;
+  static_assert(sizeof(structLinesInfo) == 80, "layout");
+  return (f != nullptr && mp.oriMapCol == 608 && pose.x == 0 && pseBin == 1024 && lsd_sca == 0.3 && z_occ_max_dis == 1) ? 0 : 1;
+}
+'''
+
+
+@pytest.mark.parametrize("case", ["on_include_path", "quoted_later_only", "basefunc_first", "no_reference_tree"])
+def test_cpp_adapter_in_the_reference_include_order(case, tmp_path):
+    """LSD/main_on_windows.cpp:5-8 includes <myLSD.h> first and <baseFunc.h> afterwards; LSD/myLSD.h:37 includes
+    <baseFunc.h> itself.  The adapter must compile in that order whether baseFunc.h is on the include path (it is then
+    included by the adapter, like the reference header does), only reachable later through a quoted include (the adapter
+    has then defined the same guard), included before the adapter, or absent."""
+    inc = os.path.join(ROOT, "include")
+    ref = tmp_path / "reftree"
+    ref.mkdir()
+    src_dir = tmp_path / "src"
+    src_dir.mkdir()
+    flags = ["-I", inc]
+    if case == "on_include_path":
+        (ref / "baseFunc.h").write_text(_BASEFUNC_DOUBLE)
+        flags += ["-I", str(ref)]
+        head = "#include <myLSD.h>\n#include <baseFunc.h>\n#ifndef TEST_SAW_REFERENCE_BASEFUNC\n#error the adapter must take the reference baseFunc.h when it is on the include path\n#endif\n#ifdef LSD_ADAPTER_OWN_BASEFUNC\n#error fallback active although baseFunc.h is reachable\n#endif"
+    elif case == "quoted_later_only":
+        (src_dir / "baseFunc.h").write_text(_BASEFUNC_DOUBLE)
+        head = '#include <myLSD.h>\n#include "baseFunc.h"\n#ifndef LSD_ADAPTER_OWN_BASEFUNC\n#error expected the fallback declarations\n#endif'
+    elif case == "basefunc_first":
+        (ref / "baseFunc.h").write_text(_BASEFUNC_DOUBLE)
+        flags += ["-I", str(ref)]
+        head = "#include <baseFunc.h>\n#include <myLSD.h>\n#include <baseFunc.h>"
+    else:
+        head = "#include <myLSD.h>\n#ifndef LSD_ADAPTER_OWN_BASEFUNC\n#error expected the fallback declarations\n#endif"
+    src = src_dir / "caller.cpp"
+    src.write_text(_CALLER % head)
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + flags + [str(src)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_cpp_adapter_opencv_branch_compiles(tmp_path):
+    """The LSD_WITH_OPENCV branch (cv::Mat in the signatures, as the reference's callers pass it) through a compiler:
+    against a test double of <opencv2/core.hpp> with cv::Mat's surface that the adapter uses (zeros -> MatExpr, ptr<T>(row),
+    rows, cols, step as cv::MatStep).  OpenCV itself is not in this image."""
+    cvdir = tmp_path / "cv" / "opencv2"
+    cvdir.mkdir(parents=True)
+    (cvdir / "core.hpp").write_text('''
+#pragma once
+#include <cstddef>
+#include <cstdlib>
+#include <memory>
+#define CV_8UC1 0
+#define CV_64FC1 6
+namespace cv {
+struct MatStep { size_t v; MatStep(size_t s = 0) : v(s) {} operator size_t() const { return v; } };
+class Mat; struct MatExpr { int r, c, t; operator Mat() const; };
+class Mat {
+public:
+    int rows = 0, cols = 0; unsigned char* data = nullptr; MatStep step;
+    Mat() {}
+    static MatExpr zeros(int r, int c, int t) { return MatExpr{r, c, t}; }
+    template <class T> T* ptr(int row = 0) { return reinterpret_cast<T*>(data + (size_t)row * (size_t)step); }
+    template <class T> const T* ptr(int row = 0) const { return reinterpret_cast<const T*>(data + (size_t)row * (size_t)step); }
+    void release() { buf.reset(); data = nullptr; }
+    std::shared_ptr<unsigned char> buf;
+};
+inline MatExpr::operator Mat() const {
+    Mat m; m.rows = r; m.cols = c; const size_t es = t == CV_64FC1 ? 8 : 1; m.step = MatStep(es * (size_t)c);
+    m.buf.reset(static_cast<unsigned char*>(std::calloc((size_t)r * es * (size_t)c + 16, 1)), std::free); m.data = m.buf.get(); return m;
+}
+}
+''')
+    src = tmp_path / "caller.cpp"
+    src.write_text('''
+#include <opencv2/core.hpp>
+#include <myLSD.h>
+using namespace cv;
+#ifndef LSD_WITH_OPENCV
+#error the adapter did not pick up OpenCV
+#endif
+int main() {
+  Mat mapValue = Mat::zeros(480, 608, CV_8UC1);
+  static_assert(sizeof(mylsd::Mat) == sizeof(cv::Mat), "mylsd::Mat is cv::Mat");
+  try {
+    Mat mapCache = mylsd::createMapCache(mapValue, 0.05);                      /* LSD/main_on_windows.cpp:67 */
+    mylsd::structLSD LSD = mylsd::myLineSegmentDetector(mapValue, 608, 480, lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin);   /* :70 */
+    return LSD.len_linesInfo < 0;
+  } catch (const mylsd::lsd_error& e) { return e.status == LSD_ERR_NO_DEVICE ? 0 : 1; }
+}
+''')
+    pkg = os.path.join(ROOT, "linesegmentdetector-slam_amd")
+    exe = tmp_path / "t"
+    p = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", str(tmp_path / "cv"), "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", pkg, "-llsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr      # no GPU here: lsd_error(NO_DEVICE) through the cv::Mat signatures

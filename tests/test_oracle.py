@@ -120,29 +120,53 @@ def test_used_map_values(maps, oracle):
     assert np.all((d["used0"] == 1) <= (d["used"] == 1))
 
 
-def test_loose_matlab_golden(maps, oracle):
-    """The reference's own golden files (data/MaplinesInfo.txt, MaplineIm.txt) come from the author's
-    MATLAB prototype: same walls, endpoints possibly swapped, a few lines differ."""
-    r = oracle.lsd(maps["mapValue"].copy())
+# Rows of data/MaplinesInfo.txt that the C++ reference does not reproduce (the file comes from the author's MATLAB prototype,
+# SURVEY section 4): measured 3.3 / 8.0 / 6.0 / 23.3 px off.  Every other row is reproduced to <= 0.064 px.
+MATLAB_ROWS_NOT_REPRODUCED = (5, 30, 37, 38)
+MATLAB_LINE_TOL_PX = 0.1
+MATLAB_RASTER_MIN_HITS = 3850          # of 3992 lit golden pixels, after the (+1, +1) shift (measured: 3865)
+
+
+def matlab_golden_check(lines, line_im, maps):
+    """The reference-held golden files for data/mapValue.txt (data/MaplinesInfo.txt, data/MaplineIm.txt), as tightly as
+    they support: >= 36 of the 40 golden lines within 0.1 px (endpoints in either order: the prototype lists them swapped),
+    with the same length and orientation sign, and >= 3850 of the 3992 lit golden pixels lit exactly, the golden raster
+    being 1-based (MATLAB) and therefore shifted by (+1, +1).  Shared with the GPU parity test: no oracle in the loop."""
     gold = maps["matlab_MaplinesInfo"]          # k b dx dy x1 y1 x2 y2 len orient
-    L = r["lines"]
-    matched = 0
-    for g in gold:
-        a = np.array([g[4], g[5]]); b = np.array([g[6], g[7]])
-        best = 1e9
-        for l in L:
-            p = np.array([l["x1"], l["y1"]]); q = np.array([l["x2"], l["y2"]])
-            e = min(max(np.abs(a - p).max(), np.abs(b - q).max()), max(np.abs(a - q).max(), np.abs(b - p).max()))
-            best = min(best, e)
-        matched += best <= 0.5
-    assert matched >= 34, matched
+    P = np.stack([lines["x1"], lines["y1"]], 1); Q = np.stack([lines["x2"], lines["y2"]], 1)
+    matched, bad_rows = 0, []
+    for gi, g in enumerate(gold):
+        a, b = g[4:6], g[6:8]
+        e_same = np.maximum(np.abs(P - a).max(1), np.abs(Q - b).max(1))
+        e_swap = np.maximum(np.abs(Q - a).max(1), np.abs(P - b).max(1))
+        e = np.minimum(e_same, e_swap)
+        j = int(np.argmin(e))
+        if e[j] <= MATLAB_LINE_TOL_PX:
+            matched += 1
+            assert abs(lines["len"][j] - g[8]) < 0.05, (gi, lines["len"][j], g[8])
+            if np.isfinite(g[0]):
+                assert int(lines["orient"][j]) == int(g[9]), gi
+                assert abs(abs(lines["dx"][j]) - abs(g[2])) < 2e-3 and abs(abs(lines["dy"][j]) - abs(g[3])) < 2e-3, gi
+        else:
+            bad_rows.append(gi)
+    assert matched >= 36, (matched, bad_rows)
+    assert tuple(bad_rows) == MATLAB_ROWS_NOT_REPRODUCED, bad_rows
     lit = maps["matlab_MaplineIm_lit_yx"]
-    im = r["lineIm"]
-    near = 0
-    for y, x in lit:
-        y0, y1, x0, x1 = max(y - 2, 0), y + 3, max(x - 2, 0), x + 3
-        near += bool(im[y0:y1, x0:x1].any())
-    assert near >= 0.9 * len(lit), (near, len(lit))
+    assert len(lit) == 3992
+    ys, xs = lit[:, 0] + 1, lit[:, 1] + 1
+    ok = (ys < line_im.shape[0]) & (xs < line_im.shape[1])
+    hits = int((line_im[ys[ok], xs[ok]] == 255).sum())
+    assert hits >= MATLAB_RASTER_MIN_HITS, hits
+    # without the shift the two rasters hardly meet: the shift is a property of the data, not a fudge
+    assert int((line_im[lit[:, 0], lit[:, 1]] == 255).sum()) < 100
+    return matched, hits
+
+
+def test_matlab_golden_pins_the_oracle(maps, oracle):
+    """The only outputs the reference itself holds for this path; they pin the oracle."""
+    r = oracle.lsd(maps["mapValue"].copy())
+    matched, hits = matlab_golden_check(r["lines"], r["lineIm"], maps)
+    assert (matched, hits) == (36, 3865)
 
 
 def test_blank_and_tiny_images(oracle):

@@ -6,7 +6,8 @@ Stated tolerances (north_star: "line-for-line within a stated endpoint/angle tol
 UsedMap indexing"):
   * GaussImage, magMap, maxGrad, sorted seed order, usedMap, lineIm, in-place remap, line count,
     orient: BIT-EXACT;
-  * degMap: <= 2 ulp (device atan2 vs glibc);
+  * degMap: <= 1 ulp (the device atan2 is correctly rounded, glibc's is within 1 ulp of that);
+  * logNFA of every seed that reaches RectangleImprover: <= 4 ulp;
   * line endpoints x1,y1,x2,y2 and len: 1e-6 px absolute; dx,dy: 1e-9; k,b: 1e-6 relative
     (transcendentals on the rectangle path differ by ulps between OCML and glibc).
 """
@@ -25,7 +26,8 @@ FIXTURES = ["map1", "mapValue", "aisle1", "aisle2", "aisle3", "f3key", "f4key"]
 ENDPOINT_TOL = 1e-6
 DIR_TOL = 1e-9
 REL_TOL = 1e-6
-DEG_ULP = 2
+DEG_ULP = 1
+NFA_ULP = 4
 
 
 @pytest.fixture(scope="module")
@@ -115,6 +117,16 @@ def test_map1_golden_line_list(maps, known, lsdmod, ctx):
                 assert abs(got[f] - float(s)) <= ENDPOINT_TOL
 
 
+def test_matlab_golden_files_directly(maps, lsdmod, ctx):
+    """The HIP path against the only outputs the reference itself holds for this path (data/MaplinesInfo.txt and
+    data/MaplineIm.txt for data/mapValue.txt) -- no oracle in the loop; same bounds as the oracle's own pin
+    (tests/test_oracle.py::test_matlab_golden_pins_the_oracle): 36 of 40 lines within 0.1 px, 3865 of 3992 raster pixels."""
+    from test_oracle import matlab_golden_check
+    lines, line_im = ctx.run(maps["mapValue"].copy())
+    matched, hits = matlab_golden_check(lines, line_im, maps)
+    assert (matched, hits) == (36, 3865)
+
+
 def test_tile2048_parity_and_known(maps, known, lsdmod, ctx, oracle):
     img = tile2048(maps["aisle1"])
     lines, line_im, _ = full_check(lsdmod, ctx, oracle, img)
@@ -136,8 +148,10 @@ def test_seed_trace_matches_oracle(maps, lsdmod, ctx, oracle):
     assert len(seeds) == len(rs)
     for f in ("order_idx", "x", "y", "num", "outcome", "final_num"):
         assert np.array_equal(seeds[f], rs[f]), f
-    acc = rs["outcome"] == 3
-    assert np.all(np.abs(seeds["logNFA"][acc] - rs["logNFA"][acc]) <= 0.11 * np.abs(rs["logNFA"][acc]) + 1e-9)
+    ev = rs["outcome"] >= 2                                                   # reached RectangleImprover (:240)
+    assert ev.sum() > 100
+    assert ulps(np.ascontiguousarray(seeds["logNFA"][ev]), np.ascontiguousarray(rs["logNFA"][ev])).max() <= NFA_ULP
+    assert not seeds["logNFA"][~ev].any() and not rs["logNFA"][~ev].any()
 
 
 def test_reference_names(maps, lsdmod, ctx, oracle):
