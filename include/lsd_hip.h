@@ -162,7 +162,7 @@ int lsd_set_region_waves(lsd_ctx *ctx, int waves);
 
 /* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
  *   GAUSS/MAG/DEG  h*w doubles      (GaussImage / magMap / degMap, myLSD.cpp:143-147)
- *   STATE          h*w uint32       low 2 bits = usedMap value (myLSD.cpp:145), rest = curMap stamp
+ *   STATE          h*w uint32       usedMap value 0 / 1 / 2 (myLSD.cpp:145)
  *   ORDER          nb uint32        sorted seed list, element = y*w + x (binCell after qsort, :204)
  *   ORDER_VAL      nb uint16        its bin values
  *   NB             1 int32          len_binCell
@@ -180,7 +180,8 @@ enum { LSD_DBG_GAUSS = 1, LSD_DBG_MAG, LSD_DBG_DEG, LSD_DBG_STATE, LSD_DBG_ORDER
 int lsd_debug_fetch(lsd_ctx *ctx, int image, int what, void *out, size_t bytes);
 
 /* Test hook: evaluates the DEVICE build of the path's transcendental functions on host arrays of n
- * doubles: fn 0 = sin/cos(a) -> out0,out1; fn 1 = atan2(a, b) -> out0; fn 2 = atan(a) -> out0. */
+ * doubles: fn 0 = sin/cos(a) -> out0,out1; fn 1 = atan2(a, b) -> out0; fn 2 = atan(a) -> out0;
+ * fn 3 = the region stage's fp32 ESTIMATE of sin/cos of the packed angle of a (its error bound is a test). */
 int lsd_debug_eval_math(lsd_ctx *ctx, int fn, const double *a, const double *b, double *out0, double *out1, size_t n);
 
 /* Profiling hook: streams `bytes` once with 8-B-per-lane stores (k_calib_write8) and once with 8-B-per-lane loads

@@ -296,10 +296,10 @@ class Context:
         if what == DBG_STATS:
             v = get(what, np.int64, 32)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                             "rrr_oob_reads", "list_spills", "cycles_total", "cycles_grow", "cycles_rect",
+                             "rrr_oob_reads", "cycles_rrr", "cycles_total", "cycles_grow", "cycles_rect",
                              "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
                              "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "resweep_batches",
-                             "cycles_group", "cycles_eval", "handed_regions", "handed_px", "cycles_idle", "cycles_select", "cycles_handed",
+                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_idle", "cycles_select", "cycles_commit",
                              "filter_skips"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
@@ -308,7 +308,8 @@ class Context:
         raise ValueError(what)
 
     def eval_math(self, fn, a, b=None):
-        """Device sin/cos (fn 0), atan2(a, b) (fn 1) or atan (fn 2) of float64 arrays (test hook)."""
+        """Device sin/cos (fn 0), atan2(a, b) (fn 1), atan (fn 2) of float64 arrays, or the region stage's fp32 estimate of
+        sin/cos of the packed angle (fn 3) (test hook)."""
         a = np.ascontiguousarray(a, np.float64)
         b = None if b is None else np.ascontiguousarray(b, np.float64)
         o0, o1 = np.zeros_like(a), np.zeros_like(a)

@@ -11,6 +11,11 @@ __global__ void k_dbgmath(int fn, const double* __restrict__ a, const double* __
     if (i >= n) return;
     if (fn == 0) { double s, c; sincos_g(a[i], s, c); o0[i] = s; o1[i] = c; }
     else if (fn == 1) { o0[i] = atan2_g(a[i], b[i]); o1[i] = 0; }
+    else if (fn == 3) {          // what RegionGrower's classifier sees: fp32 angle with 2 mantissa bits dropped, hardware sin/cos
+        const float af = __uint_as_float(__float_as_uint(__double2float_rn(a[i])) & ~3u);
+        const float r = af * 0.15915494309189535f;
+        o0[i] = (double)__builtin_amdgcn_sinf(r); o1[i] = (double)__builtin_amdgcn_cosf(r);
+    }
     else { o0[i] = atan_g(a[i]); o1[i] = 0; }
 }
 

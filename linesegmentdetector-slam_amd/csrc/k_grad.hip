@@ -2,9 +2,9 @@
 //
 // Replaces the gradient loop of myLineSegmentDetector (LSD/myLSD.cpp:152-174).
 // Algorithmic traffic: 8 B read + 8+8+1 B written per scaled pixel; this kernel
-// writes the usedMap value into the low bits of a 32-bit state word (the upper bits later hold
-// the curMap stamp of the region stage), i.e. 8 + 20 B per pixel actually move, plus 16 B for the
-// ~7 % of pixels that stay growable (sin/cos of their angle, consumed by the region stage).
+// writes the usedMap value as the low bits of the packed pixel word pw (lsd_internal.h: fp32 angle +
+// usedMap code, the only thing RegionGrower reads per neighbour), i.e. 8 + 20 B per pixel actually
+// move, plus one 16-byte (sin, cos) pair for the ~7 % of pixels that stay growable.
 #include "lsd_internal.h"
 #include "devmath.h"
 
@@ -12,6 +12,11 @@ namespace lsdhip {
 
 constexpr int GX = 64;     // columns per wavefront (one lane per column)
 constexpr int GR = 8;      // rows walked by a wavefront
+
+// fp32 angle with the two lowest mantissa bits replaced by the usedMap code (lsd_internal.h)
+__device__ __forceinline__ uint32_t pack_pw(double d, uint32_t code) {
+    return (__float_as_uint(__double2float_rn(d)) & ~3u) | code;
+}
 
 // One 64-lane workgroup owns a 64-column x 8-row strip.  Each lane walks its column downwards keeping the row
 // above in registers; the left neighbour comes from the adjacent lane (lane 0 loads it), so every gauss value is
@@ -22,8 +27,8 @@ constexpr int GR = 8;      // rows walked by a wavefront
 // zero-gradient pixels) and pushes the indices of the non-zero-gradient pixels of the strip into an LDS list;
 // phase 2 walks that list with all lanes busy.
 __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gauss, double* __restrict__ mag,
-                                                 double* __restrict__ deg, double* __restrict__ sn,
-                                                 double* __restrict__ cs, uint32_t* __restrict__ state,
+                                                 double* __restrict__ deg, double2* __restrict__ sc,
+                                                 uint32_t* __restrict__ pw,
                                                  unsigned long long* __restrict__ maxbits, int w, int h,
                                                  double gradThre) {
     __shared__ uint32_t l_px[GX * GR];       // (strip-local pixel index << 1) | growable
@@ -85,10 +90,10 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
         if (colok) {
             const size_t p = base + (size_t)y * w + x;
             mag[p] = m;
-            state[p] = u;
             if (!heavy) {
                 deg[p] = d;
-                if (u == 0) { sn[p] = 0.0; cs[p] = 1.0; }      // row 0 / col 0: angle 0 exactly, growable (Q3)
+                pw[p] = pack_pw(d, u);
+                if (u == 0) sc[p] = make_double2(0.0, 1.0);    // row 0 / col 0: angle 0 exactly, growable (Q3)
             }
         }
         const unsigned long long hm = __ballot(heavy);
@@ -119,18 +124,18 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
         double d = atan2_g(gradX, -gradY);                     // :169
         if (fabs(d - kPi) < 0.000001) d = 0;                   // :170-171
         deg[p] = d;
+        pw[p] = pack_pw(d, (e & 1u) ? kPwFree : kPwStatic);
         if (e & 1u) {                                          // sin/cos(deg) for RegionGrower (:545-546)
             double sv, cv;
             sincos_g(d, sv, cv);
-            sn[p] = sv;
-            cs[p] = cv;
+            sc[p] = make_double2(sv, cv);
         }
     }
 }
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     dim3 grid((g.w + GX - 1) / GX, (g.h + GR - 1) / GR, n);
-    hipLaunchKernelGGL(k_gradient, grid, dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sn, b.cs, b.state, b.maxbits, g.w, g.h,
+    hipLaunchKernelGGL(k_gradient, grid, dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits, g.w, g.h,
                        g.gradThre);
 }
 

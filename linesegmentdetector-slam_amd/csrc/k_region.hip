@@ -11,22 +11,21 @@
 // (== 1)?", and only ACCEPTED lines ever set a pixel to 1 (rejected regions set 2, which stays
 // growable; small/failed regions set nothing).  So the wavefronts of a workgroup evaluate seeds
 // SPECULATIVELY ahead of a commit cursor and commit in seed order:
-//   * a wave takes a block of 8 consecutive seeds, notes the accept epoch, and grows the 8 regions together
-//     in group mode (grow8(): 8 lanes per region, one frontier entry per step, private lists / stamps in HBM);
-//   * it evaluates the grown regions one by one with all 64 lanes (rectangle, Refiner incl. its regrow with
-//     the wave-wide batched grow(), NFA); results that mark nothing are published in an LDS ring, results
-//     that mark usedMap are stashed (record + pixel list) and committed when the cursor reaches them;
+//   * a wave takes the next seed (one at a time, whichever wave is free), notes the accept epoch, and evaluates
+//     it with all 64 lanes: grow() (8 frontier pixels x 8 neighbours per batch out of an LDS tile cache of packed
+//     pixel words), rectangle, Refiner incl. its regrow, NFA;
+//   * results that mark nothing are published in an LDS ring, results that mark usedMap are stashed (record +
+//     pixel list in one of the wave's result slots) and committed when the cursor reaches them;
 //   * at its turn a result is valid if its seed is still unused and no pixel it EXAMINED (a member of one of
 //     its grown lists or one of their 8 neighbours) was banned since its snapshot -- accepted pixels carry
-//     their line's epoch above the usedMap bits, the boxes of recently accepted lines are a first filter;
-//     an invalid result is evaluated again at the cursor, where everything earlier is committed;
-//   * commit = mark usedMap (1 + epoch, or 2), append the rectangle, advance the cursor.
+//     their line's epoch (epochmap), the boxes of recently accepted lines are a first filter; an invalid result
+//     is evaluated again at the cursor, where everything earlier is committed;
+//   * commit = mark usedMap (code 3 + epoch, or 2), append the rectangle, advance the cursor.
 // The committed sequence of decisions is therefore exactly the sequential one (DESIGN.md section 4 has the
 // measurements behind every choice, and the variants that were tried and dropped).
 // Inside a wavefront the lanes cooperate where the order of evaluation can be kept:
-//   * region growing: 8 regions x 8 neighbours per step (grow8) or 8 frontier pixels x 8 neighbours of ONE
-//     region per batch (grow); angle sums in reference order, candidates classified against an estimate of
-//     the region angle with a rigorous margin, exact angle only when too close to call;
+//   * region growing: candidates are classified against the ESTIMATED sum vector of the region with a rigorous
+//     margin, the exact fp64 angle sums (reference order = list order) are caught up lazily from the list;
 //   * rectangle moments: products per lane, SERIAL accumulation in list order (bit-exact sums);
 //   * NFA pixel count: the rectangle's columns are flattened with a wave prefix sum and counted
 //     with ballot/popcount;
@@ -35,7 +34,7 @@
 #include "devmath.h"
 
 // The file is compiled twice (Makefile): LSD_REGION_NW = 4 (two images per CU: the batch path, all 512 workgroups of the
-// bench batch resident at once) and LSD_REGION_NW = 8 (one image per CU, 8 speculative wavefronts per image: ~1.5x lower
+// bench batch resident at once) and LSD_REGION_NW = 8 (one image per CU, 8 speculative wavefronts per image: lower
 // latency per image, chosen when the batch leaves CUs idle anyway).  Everything lives in a per-variant namespace.
 #ifndef LSD_REGION_NW
 #define LSD_REGION_NW 4
@@ -49,67 +48,81 @@
 namespace lsdhip {
 namespace RVAR {
 
-#ifndef LSD_REGION_NW
-#define LSD_REGION_NW 4
-#endif
 #ifndef LSD_REGION_WAVES_PER_SIMD
 #define LSD_REGION_WAVES_PER_SIMD 2
 #endif
+#ifndef LSD_REGION_NS
+#define LSD_REGION_NS 8
+#endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
+constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
-constexpr int NSLOT = 4;     // tile-cache slots per wave (2 x 2 tiles)
+constexpr int NT = 32;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words)
 constexpr int RING = 128;    // remembered bounding boxes of recently accepted lines
-#ifndef LSD_REGION_NB
-#define LSD_REGION_NB 1
-#endif
-#if LSD_REGION_NB != 1
-#error "more than one block buffer per wave is not supported (the list-withdrawal at refetch assumes one; 2-4 buffers were measured slower and are untested since)"
-#endif
-constexpr int NB = LSD_REGION_NB;        // blocks of 8 seeds a wave may have in flight (evaluated, waiting for their turn to commit)
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
     int pk;
 };
 
+// Mutable per-wave state.  It lives in LDS (not in registers) so that the out-of-line stages below can take the
+// context by value and still share it; none of it is touched inside the inner loops.
+struct WState {
+    uint32_t cur_id;     // stamp of the current grow (id_base + running number)
+    int gnum;            // size of the last grow (grow order)
+    int has_copy;        // gcopy holds the grow-order list (RegionRadiusReducer reordered lst)
+    int dirty;           // stamps stored to HBM since the last fence
+    int cache_epoch;     // accept epoch the tile cache was (re)started at; -1: empty
+    int members_cached;  // the cache may hold member bits of the last grow
+    int ex_upto;         // exact angle sums of the last grow, caught up lazily in list order (myLSD.cpp:545-546)
+    double ex_sin, ex_cos;
+    Rec rec;             // the rectangle of the region being evaluated
+};
+
 struct RCtx {
-    int w, h, lane;
+    int w, h, lane, wave;
     const double* mag;
     const double* deg;
-    uint32_t* state;     // usedMap values (shared by the workgroup)
+    uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
+    uint32_t* epochmap;
     uint32_t* stamp;     // this wave's curMap stamps
     uint32_t* spill;
     uint32_t* gcopy;
-    float2* meta;        // HBM [mcap]: (angle estimate, slack) of the last full test of a list entry, see grow()
+    float4* meta;        // HBM [mcap]: (unit sum vector, sin of the smallest slack) of the last full test of a list entry, see grow()
     int mcap;
-    const double* sn;
-    const double* cs;
-    uint32_t* lst;       // LDS [LCAP]
-    uint16_t* wl0;       // LDS [LCAP] sweep worklists
-    uint16_t* wl1;
-    uint32_t* t_st;      // LDS [NSLOT][64] tile cache: state words
-    double* t_deg;       // LDS [NSLOT][64]
-    double* t_sn;        // LDS [NSLOT][64]
-    double* t_cs;        // LDS [NSLOT][64]
-    int* t_tag;          // LDS [NSLOT]
+    const double2* sc;   // (sin, cos)(deg)
     int tilesX;
-    bool dirty;          // stamps stored to HBM since the last fence
-    int* s_incl;         // LDS [64]
-    int* s_lo;           // LDS [64]
-    int* s_x;            // LDS [64]
-    uint32_t cur_id;     // stamp of the current grow (id_base + running number)
-    int gnum;            // size of the last grow (grow order)
-    bool has_copy;       // gcopy holds the grow-order list (RegionRadiusReducer reordered lst)
+    uint32_t id_base;
     double logNT;
     const double* lgamma;
     const double* ptab;
-    unsigned long long* stat;   // LDS [32] per-wave counters (see ST_* below); kept out of registers
 };
 
-enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_SPILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
+enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TRRR, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
-       ST_WAIT, ST_RESWEEP, ST_TGROUP, ST_TEVAL, ST_NHANDED, ST_PXHANDED, ST_TIDLE, ST_TSELECT, ST_THANDED, ST_SKIPPED, ST_COUNT };
-#define STAT(i, v) do { if (c.lane == 0) c.stat[i] += (unsigned long long)(v); } while (0)
+       ST_WAIT, ST_RESWEEP, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TIDLE, ST_TSELECT, ST_TCOMMIT, ST_SKIPPED, ST_COUNT };
+// STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
+// s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
+// (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
+//  coincides with a join of wave-uniform control flow makes the compiler treat the uniform loop state as divergent)
+#define STAT(i, v) do { g_stat[c.wave][i] += (unsigned long long)(v); } while (0)
+#ifdef LSD_REGION_STATS
+#define DSTAT(i, v) STAT(i, v)
+#define NOW() ((long long)__builtin_amdgcn_s_memtime())
+#else
+#define DSTAT(i, v) do { } while (0)
+#define NOW() 0ll
+#endif
+
+// Per-wave LDS storage.  Declared at namespace scope (not inside the kernel) so that the out-of-line stages address it
+// as LDS (ds_ instructions) instead of through generic pointers carried in the context (flat_ instructions).
+__shared__ uint32_t g_lst[NW][LCAP];                      // region list (packed y<<16 | x), grow order
+__shared__ uint16_t g_wl[NW][2][LCAP + 2];                // sweep worklists (+ a dummy slot for predicated stores)
+__shared__ uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
+__shared__ int g_ttag[NW][NT];
+__shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
+__shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
+__shared__ WState g_ws[NW];
 
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
@@ -119,10 +132,13 @@ __device__ __forceinline__ double rl(double v, int l) {  // broadcast lane l (l 
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float rlf(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return ((uint32_t)y << 16) | (uint32_t)x; }
-__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? c.lst[i] : c.spill[i - LCAP]; }
+__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? g_lst[c.wave][i] : c.spill[i - LCAP]; }
 __device__ __forceinline__ void lset(const RCtx& c, int i, uint32_t v) {
-    if (i < LCAP) c.lst[i] = v; else c.spill[i - LCAP] = v;
+    if (i < LCAP) g_lst[c.wave][i] = v; else c.spill[i - LCAP] = v;
 }
 __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp:540-542 / :1009-1011
     double d = fabs(a - b);
@@ -131,22 +147,24 @@ __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS tile cache: 8x8-pixel tiles of (state, deg, sin deg, cos deg), direct-mapped over a
-// 16x16-pixel window (slot = tx&1 | (ty&1)<<1).  RegionGrower reads its 3x3 neighbourhoods from
-// here, so a batch costs LDS latency instead of two dependent HBM round trips plus a store fence.
-// Accepted pixels are stamped in the LDS copy AND in HBM (write-through, never waited for); the
-// cache is dropped whenever usedMap marks change (mark_region).
+// LDS tile cache: 8x8-pixel tiles of packed pixel words, NT slots, slot = (tx + 5 ty) mod NT (rows, columns
+// and diagonals of tiles spread over all slots).  RegionGrower reads its 3x3 neighbourhoods from here, so a
+// batch costs LDS latency instead of dependent HBM round trips.  A cached word is the pixel's pw with the code
+// replaced by two flags: bit 0 = banned (code 1 or 3), bit 1 = member of the current grow (curMap).  Accepted
+// pixels are flagged in the LDS copy AND stamped in HBM (write-through, never waited for, re-read when a tile
+// comes back after an eviction).  The cache survives from seed to seed while no line is accepted in the image
+// (a tile fetched before an accept could miss a ban that the snapshot of a later seed no longer flags).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx & 1) | ((ty & 1) << 1); }
+__device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx + 5 * ty) & (NT - 1); }
 
 // Makes the tiles of every lane with need==true resident.  Returns false when two needed tiles map
 // to the same slot (the caller retries with a smaller batch; a single 3x3 neighbourhood never conflicts).
-__device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py) {
+__device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, int py) {
     const int lane = c.lane, w = c.w, h = c.h;
     const int tx = px >> 3, ty = py >> 3;
     const int tile = need ? ty * c.tilesX + tx : -1;
     const int slot = tile_slot(tx, ty);
-    unsigned long long todo = __ballot(need && c.t_tag[slot] != tile);
+    unsigned long long todo = __ballot(need && g_ttag[c.wave][slot] != tile);
     if (!todo) return true;
     // conflict check over all needed tiles (resident ones included)
     {
@@ -158,9 +176,10 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
             chk &= ~__ballot(tile == T);
         }
     }
-    const long long tt0 = (long long)__builtin_amdgcn_s_memtime();
-    if (c.dirty) { wg_fence(); c.dirty = false; }     // earlier stamps must have landed before a tile is (re)read
-    STAT(ST_TILEFETCH, 1);
+    [[maybe_unused]] const long long tt0 = NOW();
+    if (__builtin_amdgcn_readfirstlane(g_ws[c.wave].dirty)) { wg_fence(); g_ws[c.wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
+    DSTAT(ST_TILEFETCH, 1);
+    const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[c.wave].cur_id);
     while (todo) {
         // up to 4 missing tiles per round, all loads in flight together
         int T[4], S[4];
@@ -176,60 +195,87 @@ __device__ __forceinline__ bool ensure_tiles(RCtx& c, bool need, int px, int py)
                 nt++;
             }
         }
-        double vd[4], vs[4], vc[4];
-        uint32_t vw[4];
+        uint32_t vw[4], vs[4];
         #pragma unroll
         for (int j = 0; j < 4; j++) {
-            vd[j] = 0; vs[j] = 0; vc[j] = 1; vw[j] = 1u;          // outside the image: banned
+            vw[j] = kPwStatic; vs[j] = 0u;                        // outside the image: banned
             if (j < nt) {
                 const int ttx = T[j] % c.tilesX, tty = T[j] / c.tilesX;
                 const int x = ttx * 8 + (lane & 7), y = tty * 8 + (lane >> 3);
                 if (x < w && y < h) {
                     const size_t q = (size_t)y * w + x;
-                    vw[j] = (c.stamp[q] << 2) | (c.state[q] & 3u);
-                    vd[j] = c.deg[q];
-                    vs[j] = c.sn[q];                              // garbage where usedMap == 1: never read
-                    vc[j] = c.cs[q];
+                    vw[j] = c.pw[q];
+                    vs[j] = c.stamp[q];
                 }
             }
         }
         #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nt) {
-                c.t_st[S[j] * 64 + lane] = vw[j];
-                c.t_deg[S[j] * 64 + lane] = vd[j];
-                c.t_sn[S[j] * 64 + lane] = vs[j];
-                c.t_cs[S[j] * 64 + lane] = vc[j];
-                if (lane == 0) c.t_tag[S[j]] = T[j];
+                g_tw[c.wave][S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
+                g_ttag[c.wave][S[j]] = T[j];               // (all lanes, same value)
             }
         }
     }
-    wg_fence();
-    STAT(ST_TTILES, (long long)__builtin_amdgcn_s_memtime() - tt0);
+    DSTAT(ST_TTILES, NOW() - tt0);
     return true;
 }
 
-__device__ __forceinline__ void invalidate_tiles(RCtx& c) {
-    if (c.lane < NSLOT) c.t_tag[c.lane] = -1;
-    wg_fence();
+__device__ __forceinline__ void invalidate_tiles(const RCtx& c) {
+    if (c.lane < NT) g_ttag[c.wave][c.lane] = -1;
+    g_ws[c.wave].members_cached = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order); returns the size and
-// the angle sums (the region angle atan2(sinS, cosS) is evaluated by the caller only when needed).
+// The exact angle sums of the current region (sinDeg, cosDeg of RegionGrower, :545-546) over the list prefix
+// [0, n): the reference adds cos/sin(deg) of every accepted pixel in the order of acceptance, which is the list
+// order, so the sums can be caught up at any time from the list and the (sin, cos) map K2 wrote.
+// ---------------------------------------------------------------------------------------------
+// (out of line, like every per-region stage below: each gets the register file to itself, and the seed loop keeps only
+//  what it needs across the calls; the context travels by value, the mutable state sits in LDS)
+__device__ __noinline__ void exact_sums(RCtx c, int n) {
+    if (g_ws[c.wave].ex_upto >= n) return;
+    [[maybe_unused]] const long long t0 = NOW();
+    const int lane = c.lane, w = c.w;
+    double sinS = g_ws[c.wave].ex_sin, cosS = g_ws[c.wave].ex_cos;
+    for (int base = g_ws[c.wave].ex_upto; base < n; base += 64) {
+        const int kx = base + lane;
+        double vs = 0, vc = 0;
+        if (kx < n) {
+            const uint32_t pk = lget(c, kx);
+            const double2 v = c.sc[(size_t)(pk >> 16) * w + (pk & 0xffffu)];
+            vs = v.x; vc = v.y;
+        }
+        const int cnt = min(64, n - base);
+        if (cnt == 64) {
+            #pragma unroll
+            for (int j = 0; j < 64; j++) { cosS += rl(vc, j); sinS += rl(vs, j); }
+        } else
+        for (int j = 0; j < cnt; j++) { cosS += rl(vc, j); sinS += rl(vs, j); }
+    }
+    if (lane == 0) { g_ws[c.wave].ex_sin = sinS; g_ws[c.wave].ex_cos = cosS; g_ws[c.wave].ex_upto = n; }
+    DSTAT(ST_TSUMS, NOW() - t0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RegionGrower, myLSD.cpp:491-590.  Leaves the region in c.lst (grow order) and returns its size; the angle
+// sums are available through exact_sums() (the caller needs them only for regions that go on to the rectangle).
 //
-// The reference tests every candidate against regDeg = atan2(sinDeg, cosDeg) recomputed after each
-// accepted pixel (:545-547), in list order / row-major neighbour order.  Here a batch of 8 frontier
-// pixels x 8 neighbours is classified at once against an ESTIMATE of regDeg with a rigorous margin:
-//   margin = (error of the fp32 estimate) + (largest drift regDeg can undergo while the up-to-m
-//            candidates of this batch are accepted: each accepted unit vector lies within tol of the
-//            current sum vector of norm L, so it turns it by at most sin(tol)/L)
-//   * |dif| < tol - margin : passes whatever happens earlier in the batch  -> accepted in bulk
-//   * |dif| > tol + margin : fails whatever happens                        -> ignored
-//   * otherwise            : resolved one by one in reference order against a fresh estimate, and
-//                            against the correctly rounded angle when still too close to call.
-// The sums are accumulated in the reference order in every case, so they are bit-identical, and every
-// accept/reject decision is the one the exact angle would give.
+// The reference tests every candidate against regDeg = atan2(sinDeg, cosDeg) recomputed after each accepted
+// pixel (:545-547), in list order / row-major neighbour order.  For tol < pi/2 "|regDeg - deg| (wrapped) < tol"
+// is the circular distance between the candidate's direction u and the direction of the sum vector V, i.e.
+// u.V > cos(tol) |V|.  A batch of 8 frontier pixels x 8 neighbours is classified at once in that form with fp32
+// ESTIMATES of u (hardware sin/cos of the packed fp32 angle) and V (their running sum), and a rigorous margin:
+//   eps_c  error of the estimated cosine: |u - u_true| <= kEpsU per vector, so V is off by <= n kEpsU
+//   delta  largest turn of V while the up-to-m winners of this batch are accepted: each accepted unit vector lies
+//          within tol of the current sum of norm L, so it turns it by at most sin(tol)/L
+//   * cos > cos(tol) + delta sin(tol) + eps_c      : passes whatever happens earlier in the batch -> accepted in bulk
+//   * cos < cos(tol) - delta (sin(tol)+delta) - eps_c : fails whatever happens                    -> ignored
+//   * otherwise the batch is resolved pixel by pixel in reference order against the then-current estimate, and
+//     against the correctly rounded angle of the exact sums when still too close to call.
+// Every accept/reject decision is therefore the one the exact angle would give; the exact sums are accumulated in
+// reference order (exact_sums()).  Larger tolerances (Refiner may ask for any) take the pixel-by-pixel path with the
+// reference's own wrapped-difference test.
 // Sweeps after the first revisit only entries that still had a non-member, non-banned neighbour
 // (membership and bans only grow during one call, so the others cannot accept anything).
 // ---------------------------------------------------------------------------------------------
@@ -237,52 +283,118 @@ __device__ __forceinline__ void invalidate_tiles(RCtx& c) {
 // an upper bound of 1 / v for v >= 0.9 (v_rcp_f32 is good to 1 ulp; the margins it feeds are themselves upper bounds)
 __device__ __forceinline__ float inv_ub(float v) { return __builtin_amdgcn_rcpf(v) * 1.000001f; }
 
-constexpr double kAngEps = 8e-6;   // >= error of (double)atan2f((float)s,(float)c) incl. input rounding
+constexpr float kEpsU = 4e-6f;     // >= |(cos, sin) estimate - exact|: 2-bit truncation of the fp32 angle (1e-6) + v_sin/v_cos_f32
+                                   //    (tests/test_parity_gpu.py::test_fast_sincos_error_bound measures the latter)
+constexpr float kInv2Pi = 0.15915494309189535f;
 
-__device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, double tol, int& out_num,
-                                     double& out_sin, double& out_cos) {
-    const int lane = c.lane, w = c.w, h = c.h;
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    const uint32_t id = ++c.cur_id;                          // fresh curMap (:519)
+__device__ __forceinline__ void fast_sincos(float a, float& s, float& co) {   // hardware sin/cos take revolutions
+    const float r = a * kInv2Pi;
+    s = __builtin_amdgcn_sinf(r);
+    co = __builtin_amdgcn_cosf(r);
+}
+
+// Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
+// the scalar unit (scalar compares and branches, SGPR-base addressing of global memory with 32-bit lane offsets).
+#define AS1 __attribute__((address_space(1)))
+typedef float nf4 __attribute__((ext_vector_type(4)));       // (HIP's float4 class cannot be reached through an address-space pointer)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class T>
+__device__ __forceinline__ AS1 T* uglobal(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (AS1 T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int mbcnt(unsigned long long m) {   // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// minimum over the 8 lanes of a group (lane >> 3), every lane gets it: three DPP steps, no LDS traffic
+__device__ __forceinline__ float min8(float v) {
+    int t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+    t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+    t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xf, 0xf, false)));  // row_half_mirror
+    return v;
+}
+
+__device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, double tol_) {
+    const int lane = c.lane;
+    const double regDeg0 = uni(regDeg0_), tol = uni(tol_);
+    const int w = uni(c.w), h = uni(c.h), wave = uni(c.wave), tilesX = uni(c.tilesX), mcap = uni(c.mcap);
+    const int sx = uni(sx_), sy = uni(sy_);
+    AS1 uint32_t* const stamp = uglobal(c.stamp);
+    AS1 nf4* const meta = (AS1 nf4*)uglobal(c.meta);
+    c.w = w; c.h = h; c.wave = wave; c.tilesX = tilesX;      // (what the helpers below read)
+    [[maybe_unused]] const long long t0 = NOW();
+    // curMap of the previous grow: drop its member flags from the cache (:519 starts from zeros)
+    if (uni(g_ws[wave].members_cached)) {
+        const int gprev = uni(g_ws[wave].gnum);
+        if (uni(g_ws[wave].has_copy) || gprev > 4 * LCAP) invalidate_tiles(c);
+        else {
+            for (int k2 = lane; k2 < gprev; k2 += 64) {
+                const uint32_t pk = lget(c, k2);
+                const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
+                const int slot = tile_slot(x >> 3, y >> 3);
+                if (g_ttag[wave][slot] == (y >> 3) * tilesX + (x >> 3)) g_tw[wave][slot * 64 + ((y & 7) << 3) + (x & 7)] &= ~2u;
+            }
+        }
+    }
+    uint32_t id = (uint32_t)uni((int)g_ws[wave].cur_id);
+    if ((id - (uint32_t)uni((int)c.id_base)) >= 0xFFFF0u) {                      // the run's 2^20 stamp ids are used up: start over on clean stamps
+        for (size_t q = lane; q < (size_t)w * h; q += 64) stamp[q] = 0u;
+        wg_fence();
+        id = c.id_base;
+    }
+    id = (uint32_t)uni((int)id + 1);                         // fresh curMap (:519)
+    if (lane == 0) {
+        WState& ws = g_ws[wave];
+        ws.cur_id = id; ws.members_cached = 1; ws.has_copy = 0; ws.ex_upto = 0; ws.ex_sin = 0.0; ws.ex_cos = 0.0;
+    }
     ensure_tiles(c, lane == 0, sx, sy);
-    double sinS, cosS;
+    double Ce, Se;                                           // estimated sum vector
     {
         const int slot = tile_slot(sx >> 3, sy >> 3), ti = ((sy & 7) << 3) | (sx & 7);
-        sinS = c.t_sn[slot * 64 + ti];                       // sin/cos(regDeg0): regDeg0 is degMap[seed] at both call sites (:225, :857)
-        cosS = c.t_cs[slot * 64 + ti];
+        const uint32_t sw = g_tw[wave][slot * 64 + ti];
+        float s0, c0;
+        fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
+        Ce = (double)c0; Se = (double)s0;
         if (lane == 0) {
-            lset(c, 0, pack_xy(sx, sy));
-            c.t_st[slot * 64 + ti] = (id << 2) | (c.t_st[slot * 64 + ti] & 3u);   // :520
-            c.stamp[(size_t)sy * w + sx] = id;
+            g_lst[wave][0] = pack_xy(sx, sy);
+            g_tw[wave][slot * 64 + ti] = sw | 2u;            // :520
+            stamp[sy * w + sx] = id;
+            g_ws[wave].dirty = 1;
         }
-        c.dirty = true;
     }
-    // R estimates the reference's regDeg; |R - regDeg| <= eps at any time.  eps is 0 while R is the exact
-    // value, kAngEps right after an fp32 refresh, and grows by the worst-case turn of every pixel accepted
-    // since (so the estimate is refreshed only when some candidate is too close to call).
-    double R = regDeg0;
-    double eps = 0.0;
-    bool fresh = true;                                       // R was computed from the current sums
-    const bool tol_small = tol < 1.5;                        // accepted vectors then never shorten the sum
-    const double turn = tol < 1.1 ? tol : 1.1;               // >= sin(tol) resp. the asin(1/L)*L bound
-    // lower bound of the norm of the angle-sum vector: every accepted unit vector lies within tol (< pi/2) of
-    // it, so it lengthens it by at least cos(tol)
-    const float cos_lb = tol_small ? cosf((float)tol) * 0.999f - 1e-6f : 0.0f;
-    float Llb = 0.999f;
     int n = 1;
+    if (!(tol == tol)) {                                     // NaN tolerance (Refiner, :855): no test ever passes
+        if (lane == 0) g_ws[wave].gnum = 1;
+        STAT(ST_GROW, 1); STAT(ST_GROWN, 1);
+        return 1;
+    }
+    const bool tol_small = tol < 1.5;                        // the circular-distance form applies, and accepted vectors never shorten the sum
+    const float turn = (float)(tol < 1.1 ? tol : 1.1) * 1.0032f;   // >= sin(tol) resp. the asin(1/L)*L bound, x (|V| estimate / its lower bound)
+    const float tolf_lo = (float)tol * 0.9999999f;           // <= tol
+    float cos_tol, sin_tol;
+    {
+        double st, ct;
+        sincos_g(tol_small ? tol : 1.0, st, ct);
+        cos_tol = (float)ct; sin_tol = (float)st * 1.0000002f + 1e-7f;      // sin_tol >= sin(tol)
+    }
     const int e = lane >> 3, k = lane & 7;
     const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
     const int ox = kk % 3 - 1, oy = kk / 3 - 1;
-    const unsigned long long ltmask = (1ull << lane) - 1ull;
-    uint16_t* wl_cur = c.wl0;
-    uint16_t* wl_nxt = c.wl1;
-    int wl_cnt = 0;                                          // entries of wl_cur (sweep >= 2)
+    int wcur = 0;                                            // g_wl[wave][wcur] is this sweep's worklist, [wcur ^ 1] the next one's
+    int wl_cnt = 0;                                          // entries of this sweep's worklist (sweep >= 2)
     bool filter = true;                                      // false once the list outgrew the worklists
-    // Re-sweeps: an entry whose remaining candidates all failed by more than the region angle has moved since cannot
+    // Re-sweeps: an entry whose remaining candidates all failed by more than the sum vector has turned since cannot
     // accept anything now either (membership and bans only grow); it is carried over to the next worklist without
-    // touching its neighbourhood.  meta[entry] = (angle estimate its candidates were compared with, smallest
-    // "distance - tol" among the candidates left), checked 64 entries at a time.
-    unsigned long long flt_need = 0;                         // chunk [flt_base, flt_base + 64) of wl_cur: entries to test in full
+    // touching its neighbourhood.  meta[entry] = (unit sum vector its candidates were compared with, sine of the
+    // smallest "distance - tol" among the candidates left), checked 64 entries at a time.
+    unsigned long long flt_need = 0;                         // chunk [flt_base, flt_base + 64) of the worklist: entries to test in full
     int flt_base = 0;
     bool flt_valid = false;
     int sweep = 1, ex;
@@ -294,6 +406,19 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
         int i = (sweep == 1 || !filter) ? 0 : n_start;       // contiguous cursor
         bool in_wl = (sweep > 1) && filter;
         while (true) {
+            // The loop state is wave-uniform by construction, but the compiler's divergence analysis gives up on it as soon as
+            // the join of some lane-conditional store coincides with a join of the uniform control flow (which its CFG
+            // simplifications produce at will) -- and then runs the whole loop as divergent code on the vector unit.  Saying
+            // it again here costs nothing where the analysis already knows, and keeps the control flow scalar where it does not.
+            n = uni(n); i = uni(i); wi = uni(wi); nxt_cnt = uni(nxt_cnt); wl_cnt = uni(wl_cnt); flt_base = uni(flt_base);
+            in_wl = uni((int)in_wl) != 0; filter = uni((int)filter) != 0; flt_valid = uni((int)flt_valid) != 0;
+            flt_need = ((unsigned long long)(uint32_t)uni((int)(uint32_t)(flt_need >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)flt_need);
+            // ---- the estimate of this batch (same in every lane) ----
+            const float Cf = (float)Ce, Sf = (float)Se;
+            const float V2 = Cf * Cf + Sf * Sf;
+            const float rV = __builtin_amdgcn_rsqf(fmaxf(V2, 1e-12f)) * 1.000001f;   // >= 1 / |V|
+            const float Vn = V2 * rV;                                                 // |V| (to 2e-6)
+            const float nrat = (float)n * rV;                // >= n / |V|
             // ---- pick up to 8 entries ----
             int cnt, eidx;
             if (in_wl) {
@@ -301,17 +426,16 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                 cnt = min(8, wl_cnt - wi);
                 if (tol_small && filter) {
                     if (!flt_valid || wi >= flt_base + 64) {
-                        if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
                         flt_base = wi;
                         bool nd = false;
                         if (wi + lane < wl_cnt) {
-                            const int ei = (int)wl_cur[wi + lane];
+                            const int ei = (int)g_wl[wave][wcur][wi + lane];
                             nd = true;
-                            if (ei < c.mcap) {
-                                const float2 mt = c.meta[ei];
-                                float dr = fabsf((float)R - mt.x);
-                                if (dr > 3.14159265f) dr = 6.28318531f - dr;
-                                nd = !(dr + (float)eps + 1e-5f < mt.y);
+                            if (ei < mcap) {
+                                const nf4 mt = meta[ei];
+                                const float vx = Cf * rV, vy = Sf * rV;                  // current unit sum vector (norm within 3e-6 of 1)
+                                const float dotv = mt.x * vx + mt.y * vy, crs = fabsf(mt.x * vy - mt.y * vx);
+                                nd = !(dotv > 0.0f && crs + 1e-5f + 2.0f * kEpsU * nrat < mt.z);
                             }
                         }
                         flt_need = __ballot(nd);
@@ -322,411 +446,197 @@ __device__ __forceinline__ void grow(RCtx& c, int sx, int sy, double regDeg0, do
                     const unsigned long long rest = flt_need >> off;          // bit 0 = entry wi
                     const int nskip = rest ? min(__builtin_ctzll(rest), nval) : nval;
                     if (nskip > 0) {                         // a run of entries that cannot accept anything: carry them over
-                        if (nxt_cnt + nskip > LCAP) filter = false;
-                        else {
-                            if (lane < nskip) wl_nxt[nxt_cnt + lane] = wl_cur[wi + lane];
-                            nxt_cnt += nskip;
-                        }
+                        // (lane-dependent branches stay in the MIDDLE of wave-uniform blocks, see STAT)
+                        const bool room = nxt_cnt + nskip <= LCAP;
+                        g_wl[wave][wcur ^ 1][room && lane < nskip ? nxt_cnt + lane : LCAP] = g_wl[wave][wcur][min(wi + lane, LCAP - 1)];   // (no branch: dummy slot)
+                        filter = filter && room;
+                        nxt_cnt += room ? nskip : 0;
                         wi += nskip;
-                        STAT(ST_SKIPPED, nskip);
+                        DSTAT(ST_SKIPPED, nskip);
                         continue;
                     }
                     // the run of consecutive entries to test (no skipped entry in between: its check would be stale after an accept)
                     const unsigned long long inv = ~rest;
                     cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
                 }
-                eidx = e < cnt ? (int)wl_cur[wi + e] : 0;
+                eidx = e < cnt ? (int)g_wl[wave][wcur][wi + e] : 0;
             } else {
                 if (i >= n) break;                           // n is live (:529)
                 cnt = min(8, n - i);
                 eidx = i + e;
             }
             bool valid = e < cnt;
-            const uint32_t pk = valid ? lget(c, eidx) : 0u;
+            uint32_t pk;
+            if (!in_wl && i + 8 <= LCAP) pk = g_lst[wave][eidx];              // (entries past n: harmless garbage, masked by valid)
+            else pk = valid ? lget(c, eidx) : 0u;
             const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
-            bool inb = valid && nx >= 0 && ny >= 0 && nx < w && ny < h;            // :536
-            const int slot = tile_slot(nx >> 3, ny >> 3), ti = ((ny & 7) << 3) | (nx & 7);
-            const int cell = slot * 64 + ti;
-            if (__ballot(inb && c.t_tag[slot] != (ny >> 3) * c.tilesX + (nx >> 3))) {
+            bool inb = valid && (unsigned)nx < (unsigned)w && (unsigned)ny < (unsigned)h;   // :536
+            const int tx = nx >> 3, ty = ny >> 3;
+            const int slot = tile_slot(tx, ty);
+            const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
+            uint32_t word_r = g_tw[wave][cell];
+            if (__ballot(inb && g_ttag[wave][slot] != ty * tilesX + tx)) {
                 if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
                     cnt = 1;
                     valid = e < cnt;
                     inb = inb && valid;
                     ensure_tiles(c, inb, nx, ny);
                 }
+                word_r = g_tw[wave][cell];
             }
-            const int q = ny * w + nx;
-            // all per-pixel reads of the batch are issued together (cell is in range even for !inb lanes)
-            const uint32_t word_r = c.t_st[cell];
-            const double d = c.t_deg[cell], sd = c.t_sn[cell], cd = c.t_cs[cell];
-            const uint32_t word = inb ? word_r : 1u;
-            const bool cand = inb && (word >> 2) != id && (word & 3u) != 1u;       // :537 (2 is growable, Q5)
+            const bool cand = inb && (word_r & 3u) == 0u;    // :537: not in curMap, not banned (2 is growable, Q5)
             const unsigned long long candm = __ballot(cand);
-            unsigned long long acc = 0;                      // accepted lanes (one per accepted pixel)
-            unsigned long long gone = 0;                     // every lane whose pixel became a member in this batch
+            DSTAT(ST_BATCHES, 1);
             if (candm) {
+                const int q = ny * w + nx;
+                const float af = __uint_as_float(word_r & ~3u);
+                float sf, cf;
+                fast_sincos(af, sf, cf);
                 // first occurrence of every candidate pixel: a lane is a repeat iff an EARLIER entry of the batch
                 // has the pixel in its 3x3 neighbourhood (that entry's lane for it comes first in reference order)
                 bool winner = cand;
-                {
+                if (cnt > 1) {
                     const int ex0 = (int)(pk & 0xffffu), ey0 = (int)(pk >> 16);
                     for (int e2 = 0; e2 + 1 < cnt; e2++) {
                         const int px2 = __builtin_amdgcn_readlane(ex0, e2 * 8), py2 = __builtin_amdgcn_readlane(ey0, e2 * 8);
-                        if (e > e2 && abs(nx - px2) <= 1 && abs(ny - py2) <= 1) winner = false;
+                        if (e > e2 && (unsigned)(nx - px2 + 1) <= 2u && (unsigned)(ny - py2 + 1) <= 2u) winner = false;
                     }
                 }
-                // margin: error bound of R + worst-case drift while this batch's m candidates are accepted
-                const int m = __builtin_popcountll(__ballot(winner));
-                if (!tol_small) {                            // (rare: Refiner asked for a huge tolerance) no cheap norm bound
-                    if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
-                    const float sf = (float)sinS, cf = (float)cosS;
-                    Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
-                }
-                double margin = Llb >= (tol_small ? 0.9f : 3.0f)
-                                    ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7
-                                    : 1e30;
-                double raw = fabs(R - d);
-                double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;          // :540-542
-                bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
-                bool pc = !cut && dif < tol - margin;
-                bool amb = cut || (!pc && !(dif > tol + margin));
-                if (!fresh && tol_small && __ballot(cand && amb)) {
-                    // some candidate is too close to call with the drifted estimate: refresh it once and reclassify
-                    R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
-                    margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
-                    raw = fabs(R - d);
-                    dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
-                    cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
-                    pc = !cut && dif < tol - margin;
-                    amb = cut || (!pc && !(dif > tol + margin));
-                }
-                const double Rcls = R;                       // the angle dif was taken against
-                const unsigned long long P = __ballot(winner && pc);              // accepted whatever the order
-                const unsigned long long A = __ballot(cand && amb);               // every occurrence, resolved in order
-                unsigned long long todo = P | A;
-                STAT(ST_BATCHES, 1);
-                if (sweep > 1) STAT(ST_RESWEEP, 1);
-                while (todo) {
-                    const int l = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    bool take = (P >> l) & 1ull;
-                    if (!take) {
-                        if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
-                        const double dl = rl(d, l);
-                        if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
-                        double rw = fabs(R - dl);
-                        double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
-                        if (eps != 0.0 && (fabs(R) > kPi - eps || fabs(df - tol) <= eps || fabs(rw - kPi * 3 / 2.0) <= eps ||
-                                           !(tol == tol))) {
-                            R = atan2_g(sinS, cosS);         // :547, too close to call with the estimate
-                            eps = 0.0;
-                            fresh = true;
-                            STAT(ST_EXACT, 1);
-                            rw = fabs(R - dl);
-                            df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                unsigned long long gone = 0;                 // every lane whose pixel became a member in this batch
+                bool bulk = false;
+                float dot = 0.0f;
+                if (tol_small) {
+                    const float m = (float)__builtin_popcountll(__ballot(winner));
+                    dot = cf * Cf + sf * Sf;                                          // ~ cos(distance) * |V|
+                    const float eps_c = kEpsU * (1.0f + 2.1f * nrat) + 5e-6f;         // incl. the error of Vn
+                    const float delta = m * turn * rV + 1e-7f;                        // |V| >= 1 here: accepted vectors only lengthen the sum
+                    const float t_hi = delta <= tolf_lo ? (cos_tol + delta * sin_tol + eps_c) * Vn : 3e38f;
+                    const float t_lo = delta <= 1.6f ? (cos_tol - delta * fminf(1.0f, sin_tol + delta) - eps_c) * Vn : -3e38f;
+                    const unsigned long long pcm = __ballot(cand && dot > t_hi);      // candidates that clearly pass
+                    const unsigned long long failm = __ballot(cand && dot < t_lo);    // ... clearly fail
+                    bulk = (candm & ~(pcm | failm)) == 0ull;
+                    if (bulk && pcm) {
+                        const unsigned long long P = __ballot(winner && ((pcm >> lane) & 1ull));
+                        const int np = __builtin_popcountll(P);
+                        if ((P >> lane) & 1ull) {
+                            const int idx = n + mbcnt(P);
+                            g_tw[wave][cell] = word_r | 2u;                           // :549
+                            stamp[q] = id;
+                            if (n + 64 <= LCAP) g_lst[wave][idx] = pack_xy(nx, ny);   // :551-556
+                            else lset(c, idx, pack_xy(nx, ny));
                         }
-                        take = df < tol;                     // :543
-                    }
-                    if (take) {
-                        cosS += rl(cd, l);                   // :545
-                        sinS += rl(sd, l);                   // :546
-                        // the estimate drifts by at most turn / |sum| per accepted pixel
-                        eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * inv_ub(Llb)) + 1e-9 : 1e30;
-                        Llb += cos_lb;
-                        fresh = false;
-                        acc |= 1ull << l;
-                        if (!((P >> l) & 1ull)) gone |= __ballot(cand && q == __builtin_amdgcn_readlane(q, l));
+                        float ps = 0.0f, pc2 = 0.0f;
+                        unsigned long long todo = P;
+                        while (todo) {
+                            const int l = __builtin_ctzll(todo);
+                            todo &= todo - 1ull;
+                            pc2 += rlf(cf, l); ps += rlf(sf, l);
+                        }
+                        Ce += (double)pc2; Se += (double)ps;
+                        n += np;
+                        g_ws[wave].dirty = 1;                // (all lanes, same value: see STAT)
+                        flt_valid = false;                   // the region angle moved
+                        gone = pcm;
                     }
                 }
-                if (acc) {
-                    const bool mine = (acc >> lane) & 1ull;
-                    if (mine) {
-                        c.t_st[cell] = (id << 2) | (word & 3u);   // :549
-                        c.stamp[q] = id;
-                        lset(c, n + __builtin_popcountll(acc & ltmask), pack_xy(nx, ny));   // :551-556
+                if (!bulk) {
+                    // ---- pixel by pixel, in reference order (lane order) ----
+                    DSTAT(ST_SLOW, 1);
+                    unsigned long long todo = candm;
+                    while (todo) {
+                        const int l = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
+                        const float cl = rlf(cf, l), sl = rlf(sf, l);
+                        const float Cg = (float)Ce, Sg = (float)Se;
+                        const float Vg = sqrtf(Cg * Cg + Sg * Sg);
+                        const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
+                        int decided = -1;                    // 1 take, 0 reject, -1 exact test needed
+                        if (tol_small) {
+                            const float d1 = cl * Cg + sl * Sg;
+                            const float ec = kEpsU * (1.0f + 2.1f * nr) + 5e-6f;
+                            if (d1 > (cos_tol + ec) * Vg) decided = 1;
+                            else if (d1 < (cos_tol - ec) * Vg) decided = 0;
+                        } else if (Vg > 0.05f) {
+                            // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
+                            const double R = n == 1 ? regDeg0 : atan2((double)Se, (double)Ce);
+                            const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
+                            const double al = (double)rlf(af, l);
+                            const double rw = fabs(R - al);
+                            const double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                            if (!(fabs(R) > kPi - er || fabs(df - tol) <= er || fabs(rw - kPi * 3 / 2.0) <= er)) decided = df < tol ? 1 : 0;
+                        }
+                        decided = uni(decided);              // (the same in every lane; computed on the vector unit)
+                        const int ql = __builtin_amdgcn_readlane(q, l);
+                        if (decided < 0) {
+                            exact_sums(c, n);
+                            const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
+                            DSTAT(ST_EXACT, 1);
+                            decided = uni(angle_diff(R, c.deg[ql]) < tol ? 1 : 0);              // :540-543
+                        }
+                        if (decided == 1) {
+                            if (lane == l) {
+                                g_tw[wave][cell] = word_r | 2u;                       // :549
+                                stamp[q] = id;
+                                lset(c, n, pack_xy(nx, ny));                          // :551-556
+                            }
+                            Ce += (double)cl; Se += (double)sl;
+                            n++;
+                            g_ws[wave].dirty = 1;
+                            flt_valid = false;
+                            gone |= __ballot(cand && q == ql);
+                        }
                     }
-                    n += __builtin_popcountll(acc);
-                    c.dirty = true;
-                    flt_valid = false;                       // the region angle moved
                 }
                 // entries that still have a growable non-member neighbour go to the next sweep's worklist
-                const unsigned long long left = candm & ~gone & ~__ballot(cand && pc);
+                const unsigned long long left = candm & ~gone;
                 if (filter && left) {
                     const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
-                    if (tol_small) {                         // slack of this entry's remaining candidates (circular distance - tol)
-                        float mg = 3.0e38f;
+                    if (tol_small) {
+                        // slack of this entry's remaining candidates: sin(distance - tol), from the start-of-batch estimate;
+                        // after a pixel-by-pixel batch the sum has moved in between, so no slack is claimed (0 = test in full next time)
+                        float sg = 2.0f;
                         if ((left >> lane) & 1ull) {
-                            const double rw = fabs(Rcls - d);
-                            mg = (float)((rw > kPi ? 2.0 * kPi - rw : rw) - tol);
+                            if (bulk) {
+                                const float ct = fminf(fmaxf(dot * rV, -1.0f), 1.0f);
+                                const float st = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
+                                const float cs_ = ct * cos_tol + st * sin_tol;            // cos(distance - tol)
+                                sg = cs_ <= 0.0f ? 1.0f : st * cos_tol - ct * sin_tol;    // sin(distance - tol), 1 beyond a quarter turn
+                            } else sg = 0.0f;
                         }
-                        mg = fminf(mg, __shfl_xor(mg, 1)); mg = fminf(mg, __shfl_xor(mg, 2)); mg = fminf(mg, __shfl_xor(mg, 4));
-                        if (has && k == 0 && eidx < c.mcap) c.meta[eidx] = make_float2((float)Rcls, mg - 4e-6f);
+                        sg = min8(sg);
+                        if (has && k == 0 && eidx < mcap)
+                            meta[eidx] = nf4{Cf * rV, Sf * rV, sg - 1.2e-4f - 8.0f * kEpsU * nrat, 0.0f};
                     }
                     const unsigned long long hm = __ballot(has && k == 0);
                     const int add = __builtin_popcountll(hm);
-                    if (nxt_cnt + add > LCAP || n > 65535) filter = false;
-                    else {
-                        if (has && k == 0) wl_nxt[nxt_cnt + __builtin_popcountll(hm & ltmask)] = (uint16_t)eidx;
-                        nxt_cnt += add;
-                    }
+                    const bool room = nxt_cnt + add <= LCAP && n <= 65535;
+                    g_wl[wave][wcur ^ 1][room && has && k == 0 ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
+                    filter = filter && room;
+                    nxt_cnt += room ? add : 0;
                 }
             }
             if (in_wl) wi += cnt; else i += cnt;
         }
-        uint16_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
+        wcur ^= 1;
         wl_cnt = nxt_cnt;
         sweep++;
         flt_valid = false;
-        wg_fence();                                          // meta[] written in this sweep is read in the next
+        if (n != ex) wg_fence();                             // meta[] written in this sweep is read in the next
     } while (n != ex);
-    c.gnum = n;
-    c.has_copy = false;
+    if (lane == 0) g_ws[wave].gnum = n;
     STAT(ST_GROW, 1);
     STAT(ST_GROWN, n);
-    if (n > LCAP) STAT(ST_SPILL, 1);
-    if (c.lane == 0 && (unsigned long long)n > c.stat[ST_MAXREG]) c.stat[ST_MAXREG] = (unsigned long long)n;
-    STAT(ST_TGROW, (long long)__builtin_amdgcn_s_memtime() - t0);
-    out_num = n;
-    out_sin = sinS;
-    out_cos = cosS;
-}
-
-// ---------------------------------------------------------------------------------------------
-// grow8(): RegionGrower for EIGHT seeds at once, one seed per group of 8 lanes (lane = group*8 + neighbour).
-//
-// The serial chain of RegionGrower keeps one wavefront busy with a single frontier pixel per step in the
-// common case (thin structures grow one pixel at a time), which leaves 56 of 64 lanes idle.  Here every group
-// runs the same state machine on its own region -- one frontier entry per step, its 8 neighbours on the
-// group's 8 lanes -- so one instruction stream advances eight regions.  Per-group state lives in registers
-// (identical in the 8 lanes of a group); the region list, the sweep worklists and the curMap stamps of a group
-// are private arrays in HBM, the last 64 list entries are mirrored in an LDS ring (the frontier is at the tail).
-// Semantics per group are exactly those of grow(): reference order of the tests (entry by entry, neighbours
-// row-major), sums accumulated in that order, estimate + rigorous margin with exact fallback, worklist sweeps.
-// ---------------------------------------------------------------------------------------------
-constexpr int NG = 8;
-#ifndef LSD_G8_MIN_STEPS
-#define LSD_G8_MIN_STEPS 48
-#endif
-#ifndef LSD_G8_MIN_ACTIVE
-#define LSD_G8_MIN_ACTIVE 1
-#endif
-constexpr int G8_MIN_STEPS = LSD_G8_MIN_STEPS;    // group mode always runs this many steps ...
-constexpr int G8_MIN_ACTIVE = LSD_G8_MIN_ACTIVE;  // ... and goes on while at least this many of the 8 regions are still growing
-                                                  // (1 = to the end: since the group step got cheaper than a wave-wide batch per pixel,
-                                                  //  only regions that outgrow their list slot are handed over)
-
-struct G8 {                      // per-lane results (identical within a group)
-    int n;                       // region size; -1: list capacity exceeded (caller falls back to grow())
-    double sinS, cosS;
-    int bx0, by0, bx1, by1;      // bounding box of the region
-};
-
-__device__ __forceinline__ unsigned grp_bits(unsigned long long m, int g) { return (unsigned)((m >> (8 * g)) & 0xffull); }
-__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
-
-// (out of line on purpose: inlined into the seed loop its step loop spills to scratch, and a scratch reload per step is a memory
-//  round trip on the critical path; as a function it gets the register file to itself and saves the caller's registers once)
-struct G8Ctx {                   // what grow8 needs of RCtx, passed by value
-    int w, h, lane;
-    const double* deg;
-    const double* sn;
-    const double* cs;
-    const uint32_t* state;
-    unsigned long long* stat;
-};
-
-__device__ __noinline__ G8 grow8(G8Ctx c, bool act, int sx, int sy, uint32_t* glist, uint32_t* gwl, uint16_t* gstamp,
-                                 uint16_t id, uint32_t* ring, int gcap, double tol) {
-    G8 out;
-    const int lane = c.lane, w = c.w, h = c.h;
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    const int g = lane >> 3, j = lane & 7, gbase = g * 8;
-    const int kk = j + (j >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
-    const int ox = kk % 3 - 1, oy = kk / 3 - 1;
-    uint32_t* rg8 = ring + g * 64;
-    uint32_t* wl_cur = gwl;
-    uint32_t* wl_nxt = gwl + gcap;
-
-    // seed (:512-520)
-    double sinS = 0, cosS = 1, R = 0;
-    if (act) {
-        const size_t q0 = (size_t)sy * w + sx;
-        R = c.deg[q0]; sinS = c.sn[q0]; cosS = c.cs[q0];     // regDeg, sin/cos(regDeg) (:515-516)
-        if (j == 0) {
-            __hip_atomic_store(&gstamp[q0], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            glist[0] = pack_xy(sx, sy); rg8[0] = pack_xy(sx, sy);
-        }
-    }
-    double eps = 0.0;
-    bool fresh = true;
-    const bool tol_small = tol < 1.5;
-    const double turn = tol < 1.1 ? tol : 1.1;
-    const float cos_lb = tol_small ? cosf((float)tol) * 0.999f - 1e-6f : 0.0f;
-    float Llb = 0.999f;
-    int n = 1, i = 0, ex = 1, wi = 0, wl_cnt = 0, nxt_cnt = 0;
-    bool in_wl = false, filter = true, done = !act, overflow = false;
-    wg_fence();
-
-    int steps = 0;
-    while (true) {
-        const unsigned long long live = __ballot(!done);
-        if (!live) break;
-        // Eight regions share every step; once most of them are finished the few long ones are cheaper in the
-        // batched wave-wide grow() (8 frontier pixels per step for ONE region): hand them over (n = -1).
-        if (++steps > G8_MIN_STEPS && __builtin_popcountll(live) < 8 * G8_MIN_ACTIVE) {
-            if (!done) { overflow = true; done = true; }
-            break;
-        }
-        // ---- pick this group's next entry (one per step) ----
-        bool have = false;
-        int eidx = 0;
-        if (!done) {
-            if (in_wl) {
-                if (wi < wl_cnt) { eidx = (int)wl_cur[wi]; have = true; }
-                else in_wl = false;
-            }
-            if (!have && !in_wl) {
-                if (i < n) { eidx = i; have = true; }        // n is live (:529)
-                else {                                       // sweep finished (:525)
-                    uint32_t* t = wl_cur; wl_cur = wl_nxt; wl_nxt = t;
-                    wl_cnt = nxt_cnt; nxt_cnt = 0; wi = 0;
-                    if (n == ex) done = true;
-                    else { ex = n; in_wl = filter; i = filter ? n : 0; }
-                }
-            }
-        }
-        uint32_t pk = 0;
-        if (have) pk = (n - eidx <= 64) ? rg8[eidx & 63] : glist[eidx];
-        const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
-        const bool inb = have && nx >= 0 && ny >= 0 && nx < w && ny < h;                  // :536
-        const size_t q = (size_t)(inb ? ny : 0) * w + (inb ? nx : 0);
-        uint32_t uw = 1u; uint16_t st = 0;
-        double d = 0, sd = 0, cd = 0;
-        if (inb) {
-            uw = c.state[q];
-            // the group's own 16-bit stamps are re-read right after being stored: go to L2 (sc1), not through the CU's L1
-            st = __hip_atomic_load(&gstamp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d = c.deg[q]; sd = c.sn[q]; cd = c.cs[q];
-        }
-        const bool cand = inb && st != id && (uw & 3u) != 1u;                             // :537 (2 is growable, Q5)
-        const unsigned cb = grp_bits(__ballot(cand), g);
-        const int m = __builtin_popcount(cb);
-        if (!tol_small && cb) {                              // (rare) no cheap norm bound: refresh every step
-            if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
-            const float sf = (float)sinS, cf = (float)cosS;
-            Llb = sqrtf(sf * sf + cf * cf) * 0.999f - (float)m;
-        }
-        double margin = Llb >= (tol_small ? 0.9f : 3.0f) ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
-        double raw = fabs(R - d);
-        double dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;                   // :540-542
-        bool cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
-        bool pc = !cut && dif < tol - margin;
-        bool amb = cut || (!pc && !(dif > tol + margin));
-        unsigned ab = grp_bits(__ballot(cand && amb), g);
-        if (!fresh && tol_small && ab) {                     // too close to call with the drifted estimate: refresh once
-            R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true;
-            margin = Llb >= 0.9f ? eps + (double)(1.002f * (float)m * (float)turn * inv_ub(Llb)) + 1e-7 : 1e30;
-            raw = fabs(R - d);
-            dif = raw > kPi * 3 / 2.0 ? fabs(raw - 2.0 * kPi) : raw;
-            cut = fabs(R) > kPi - margin || fabs(raw - kPi * 3 / 2.0) <= margin;
-            pc = !cut && dif < tol - margin;
-            amb = cut || (!pc && !(dif > tol + margin));
-        }
-        const unsigned long long pm = __ballot(cand && pc), am = __ballot(cand && amb);
-        const unsigned pb = grp_bits(pm, g);
-        ab = grp_bits(am, g);
-        unsigned accb = 0;
-        // ---- the chain: neighbour jj of every group takes its turn (reference order inside a group) ----
-        // (only the neighbour positions some group has work at: the union over the groups, folded on the scalar unit)
-        unsigned long long fold = pm | am;
-        fold |= fold >> 32; fold |= fold >> 16; fold |= fold >> 8;
-        unsigned any8 = (unsigned)fold & 0xffu;
-        #pragma unroll 1
-        while (any8) {
-            const int jj = __builtin_ctz(any8);
-            any8 &= any8 - 1u;
-            const unsigned bit = 1u << jj;
-            const bool isp = (pb & bit) != 0u, isa = (ab & bit) != 0u;
-            bool take = isp;
-            if (isa) {
-                const double dl = shfl_d(d, gbase + jj);
-                if (!fresh) { R = (double)atan2f((float)sinS, (float)cosS); eps = kAngEps; fresh = true; }
-                double rw = fabs(R - dl);
-                double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
-                if (eps != 0.0 && (fabs(R) > kPi - eps || fabs(df - tol) <= eps || fabs(rw - kPi * 3 / 2.0) <= eps || !(tol == tol))) {
-                    R = atan2_g(sinS, cosS);                 // :547, too close to call with the estimate
-                    eps = 0.0; fresh = true;
-                    STAT(ST_EXACT, 1);
-                    rw = fabs(R - dl);
-                    df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
-                }
-                take = df < tol;                             // :543
-            }
-            const double cdl = shfl_d(cd, gbase + jj), sdl = shfl_d(sd, gbase + jj);
-            if (take) {
-                cosS += cdl;                                 // :545
-                sinS += sdl;                                 // :546
-                eps = (eps < 1e29 && Llb >= 0.9f) ? eps + (double)(1.002f * (float)turn * inv_ub(Llb)) + 1e-9 : 1e30;
-                Llb += cos_lb;
-                fresh = false;
-                accb |= bit;
-            }
-        }
-        // ---- commit the accepted neighbours (:549-556) ----
-        if (accb) {
-            const int na = __builtin_popcount(accb);
-            if (n + na > gcap) { overflow = true; done = true; }
-            else {
-                if (accb & (1u << j)) {
-                    const int idx = n + __builtin_popcount(accb & ((1u << j) - 1u));
-                    const uint32_t pv = pack_xy(nx, ny);
-                    __hip_atomic_store(&gstamp[q], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    glist[idx] = pv;
-                    rg8[idx & 63] = pv;
-                }
-                n += na;
-            }
-        }
-        // entries that still have a growable non-member neighbour go to the next sweep's worklist
-        if (have && filter && (cb & ~(pb | accb))) {
-            if (nxt_cnt >= gcap) filter = false;
-            else { if (j == 0) wl_nxt[nxt_cnt] = (uint32_t)eidx; nxt_cnt++; }
-        }
-        if (have) { if (in_wl) wi++; else i++; }
-        wg_fence();                                          // this step's stamps / list / worklist stores precede the next step's loads
-    }
-    // bounding boxes (for the speculation check), 8 lanes per region
-    int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-    if (act && !overflow) {
-        for (int e2 = j; e2 < n; e2 += 8) {
-            const uint32_t pv = (n - e2 <= 64) ? rg8[e2 & 63] : glist[e2];
-            const int x = (int)(pv & 0xffffu), y = (int)(pv >> 16);
-            x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
-        }
-    }
-    for (int off = 4; off >= 1; off >>= 1) {
-        x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
-        x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
-    }
-    if (act && j == 0) {
-        atomicAdd(&c.stat[ST_GROW], 1ull);
-        atomicAdd(&c.stat[ST_GROWN], (unsigned long long)n);
-        atomicMax(&c.stat[ST_MAXREG], (unsigned long long)n);
-    }
-    out.n = overflow ? -1 : n;
-    out.sinS = sinS; out.cosS = cosS;
-    out.bx0 = x0; out.by0 = y0; out.bx1 = x1; out.by1 = y1;
-    STAT(ST_TGROW, (long long)__builtin_amdgcn_s_memtime() - t0);
-    return out;
+    DSTAT(ST_TGROW, NOW() - t0);
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------
 // CenterGetter (:592-619) + OrientationGetter (:621-667) + RectangleConverter (:669-734)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, double aliPro, int pk, double tol,
-                                          Rec& r) {
+__device__ __noinline__ void rect_convert(RCtx c, int num, double regdeg, double aliPro, int pk, double tol) {
     const int lane = c.lane, w = c.w;
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    [[maybe_unused]] const long long t0 = NOW();
     double cenX = 0, cenY = 0, ws = 0;
     for (int base = 0; base < num; base += 64) {                                   // :608-613
         const int kx = base + lane;
@@ -805,13 +715,16 @@ __device__ __forceinline__ void rect_convert(RCtx& c, int num, double regdeg, do
         widMin = fmin(widMin, __shfl_xor(widMin, off));
         widMax = fmax(widMax, __shfl_xor(widMax, off));
     }
-    r.x1 = cenX + lenMin * dx; r.y1 = cenY + lenMin * dy;                          // :717-720
-    r.x2 = cenX + lenMax * dx; r.y2 = cenY + lenMax * dy;
-    r.wid = widMax - widMin;
-    r.cX = cenX; r.cY = cenY; r.deg = inertiaDeg; r.dx = dx; r.dy = dy;
-    r.p = aliPro; r.prec = tol; r.pk = pk;
-    if (r.wid < 1) r.wid = 1;                                                      // :730
-    STAT(ST_TRECT, (long long)__builtin_amdgcn_s_memtime() - t0);
+    if (lane == 0) {
+        Rec& r = g_ws[c.wave].rec;
+        r.x1 = cenX + lenMin * dx; r.y1 = cenY + lenMin * dy;                      // :717-720
+        r.x2 = cenX + lenMax * dx; r.y2 = cenY + lenMax * dy;
+        r.wid = widMax - widMin;
+        r.cX = cenX; r.cY = cenY; r.deg = inertiaDeg; r.dx = dx; r.dy = dy;
+        r.p = aliPro; r.prec = tol; r.pk = pk;
+        if (r.wid < 1) r.wid = 1;                                                  // :730
+    }
+    DSTAT(ST_TRECT, NOW() - t0);
 }
 
 __device__ __forceinline__ double rec_density(int num, const Rec& r) {             // :757,:798,:827,:867
@@ -822,17 +735,24 @@ __device__ __forceinline__ double rec_density(int num, const Rec& r) {          
 // ---------------------------------------------------------------------------------------------
 // RegionRadiusReducer, myLSD.cpp:736-802 (incl. the `i <= num` sentinel behaviour)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool radius_reduce_body(RCtx& c, int sx, int sy, int& num, double regdeg, Rec& rec,
-                                                double denThre) {
+// Returns the new region size, or -(size + 1) when the region is given up (:792).  The rectangle is g_ws[c.wave].rec.
+__device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, double regdeg, double denThre);
+__device__ __noinline__ int radius_reduce(RCtx c, int sx, int sy, int num, double regdeg, double denThre) {
+    [[maybe_unused]] const long long t0 = NOW();
+    const int r = radius_reduce_impl(c, sx, sy, num, regdeg, denThre);
+    DSTAT(ST_TRRR, NOW() - t0);
+    return r;
+}
+__device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, double regdeg, double denThre) {
     const int lane = c.lane, w = c.w;
     STAT(ST_RRR, 1);
-    double den = rec_density(num, rec);
-    if (den > denThre) return true;                                                // :760
+    double den = rec_density(num, g_ws[c.wave].rec);
+    if (den > denThre) return num;                                                 // :760
     // keep the grow-order list for the marking loops before it gets reordered
     for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
-    c.has_copy = true;
+    if (lane == 0) { g_ws[c.wave].has_copy = 1; g_ws[c.wave].dirty = 0; }
     wg_fence();
-    c.dirty = false;
+    const Rec rec = g_ws[c.wave].rec;
     const double ax = sx - rec.x1, ay = sy - rec.y1, bx = sx - rec.x2, by = sy - rec.y2;
     const double rad1 = sqrt(ax * ax + ay * ay), rad2 = sqrt(bx * bx + by * by);    // :768-769
     double rad = rad1 > rad2 ? rad1 : rad2;
@@ -866,26 +786,11 @@ __device__ __forceinline__ bool radius_reduce_body(RCtx& c, int sx, int sy, int&
             }
             i++;
         }
-        if (num < 2) return false;                                                 // :792
-        rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec, rec);                // :797
-        den = rec_density(num, rec);
+        if (num < 2) return -(num + 1);                                            // :792
+        rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec);                     // :797 (p, prec unchanged)
+        den = rec_density(num, g_ws[c.wave].rec);
     }
-    return true;
-}
-
-// Cold path (a handful of calls per image): kept out of line, with the context passed BY VALUE so that the
-// caller's context stays in registers.  *copied_out tells the caller that lst was reordered (gcopy holds the
-// grow-order list).
-__device__ __noinline__ bool radius_reduce(RCtx c, int sx, int sy, int* num_io, double regdeg, Rec* rec_io,
-                                           double denThre, int* copied_out) {
-    int num = *num_io;
-    Rec rec = *rec_io;
-    c.has_copy = false;
-    const bool ok = radius_reduce_body(c, sx, sy, num, regdeg, rec, denThre);
-    *num_io = num;
-    *rec_io = rec;
-    *copied_out = c.has_copy ? 1 : 0;
-    return ok;
+    return num;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -901,7 +806,7 @@ __device__ double log_gamma_dev(const RCtx& c, int x) {
 // ---------------------------------------------------------------------------------------------
 // RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
+__device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const int lane = c.lane, xLim = c.w, yLim = c.h;
     const double logNT = c.logNT;
     STAT(ST_NFA, 1);
@@ -955,25 +860,23 @@ __device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
         }
         const int tot = __builtin_amdgcn_readlane(inc, 63);
         if (tot == 0) continue;
-        c.s_incl[lane] = inc; c.s_lo[lane] = lo; c.s_x[lane] = xr;
-        wg_fence();
+        g_sincl[c.wave][lane] = inc; g_slo[c.wave][lane] = lo; g_sx[c.wave][lane] = xr;
         all += tot;
-        STAT(ST_NFAPX, tot);
+        DSTAT(ST_NFAPX, tot);
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
             bool hit = false;
             if (t < tot) {
                 int ci = 0;                                    // smallest ci with s_incl[ci] > t
                 for (int step = 32; step >= 1; step >>= 1)
-                    if (c.s_incl[ci + step - 1] <= t) ci += step;
-                const int ex = ci ? c.s_incl[ci - 1] : 0;
-                const int j = c.s_lo[ci] + (t - ex);
-                const double dv = c.deg[(size_t)j * xLim + c.s_x[ci]];
+                    if (g_sincl[c.wave][ci + step - 1] <= t) ci += step;
+                const int ex = ci ? g_sincl[c.wave][ci - 1] : 0;
+                const int j = g_slo[c.wave][ci] + (t - ex);
+                const double dv = c.deg[(size_t)j * xLim + g_sx[c.wave][ci]];
                 hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
             }
             ali += __builtin_popcountll(__ballot(hit));
         }
-        wg_fence();
     }
     if (all == 0 || ali == 0) return -logNT;                                       // :1019-1022
     const double logp = c.ptab[rec.pk * 3 + 0], log10p = c.ptab[rec.pk * 3 + 1], log1mp = c.ptab[rec.pk * 3 + 2];
@@ -1002,18 +905,18 @@ __device__ __forceinline__ double rect_nfa_impl(RCtx& c, const Rec& rec) {
     return -log10(binTail) - logNT;
 }
 
-__device__ __forceinline__ double rect_nfa(RCtx& c, const Rec& rec) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+__device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec) {
+    [[maybe_unused]] const long long t0 = NOW();
     const double v = rect_nfa_impl(c, rec);
-    STAT(ST_TNFA, (long long)__builtin_amdgcn_s_memtime() - t0);
+    DSTAT(ST_TNFA, NOW() - t0);
     return v;
 }
 
 // RectangleImprover, myLSD.cpp:1061-1158.  The reference's five hand-unrolled phases are walked by one
 // loop (step 0 = the initial evaluation, then 5 phases x 5 tries) so that the NFA code is inlined once.
-__device__ __forceinline__ double improve(RCtx& c, Rec& rec_io) {
+__device__ __noinline__ double improve(RCtx c) {
     const double delt = 0.5, delt2 = delt / 2.0;
-    Rec best = rec_io, r = rec_io;
+    Rec best = g_ws[c.wave].rec, r = best;
     double bestNFA = 0;
     for (int step = 0; step <= 25; step++) {
         const int phase = step == 0 ? -1 : (step - 1) / 5;
@@ -1044,15 +947,17 @@ __device__ __forceinline__ double improve(RCtx& c, Rec& rec_io) {
         if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
         else if (v > bestNFA) { bestNFA = v; best = r; }
     }
-    rec_io = best;
+    if (c.lane == 0) g_ws[c.wave].rec = best;
     return bestNFA;
 }
 
 // Refiner, myLSD.cpp:804-880, first half: the re-estimated angle tolerance (:833-855).  The regrow (:857),
 // the refit (:866) and the density checks are in the caller's two-pass loop so that grow() and
 // rect_convert() are inlined once.
-__device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, const Rec& rec, double cenDeg) {
+__device__ __noinline__ double refine_tol(RCtx c, int sx, int sy, int num, double cenDeg) {
     const int lane = c.lane, w = c.w;
+    [[maybe_unused]] const long long t0 = NOW();
+    const double rwid = g_ws[c.wave].rec.wid;
     double difSum = 0, squSum = 0;
     int ptNum = 0;
     for (int base = 0; base < num; base += 64) {                                   // :839-853
@@ -1063,7 +968,7 @@ __device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, c
             const uint32_t pkx = lget(c, kx);
             const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
             const double ddx = sx - x, ddy = sy - y;
-            if (sqrt(ddx * ddx + ddy * ddy) < rec.wid) {
+            if (sqrt(ddx * ddx + ddy * ddy) < rwid) {
                 flag = true;
                 degDif = c.deg[(size_t)y * w + x] - cenDeg;
                 while (degDif <= -kPi) degDif += 2 * kPi;
@@ -1081,6 +986,7 @@ __device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, c
         }
     }
     const double meanDif = difSum / (ptNum * 1.0);
+    DSTAT(ST_TREFINE, NOW() - t0);
     return 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
 }
 
@@ -1088,20 +994,26 @@ __device__ __forceinline__ double refine_tol(RCtx& c, int sx, int sy, int num, c
 // seed loop, myLSD.cpp:219-272
 // ---------------------------------------------------------------------------------------------
 // usedMap marking (:243-248 / :259-265) restricted to the grown pixels; returns their bounding box.
-__device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, const uint32_t* src, int src_cnt, int& bx0, int& by0, int& bx1,
-                                            int& by1) {
+// epoch1 == 0: a rejected region (usedMap = 2); else an accepted line of epoch epoch1 - 1 (usedMap = 1).
+struct Box { int x0, y0, x1, y1; };
+
+__device__ __noinline__ Box mark_region(RCtx c, uint32_t epoch1, const uint32_t* src, int src_cnt) {
     const int w = c.w;
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    [[maybe_unused]] const long long t0 = NOW();
     wg_fence();                                   // the stamps written by grow() must have landed
-    c.dirty = false;
+    if (c.lane == 0) g_ws[c.wave].dirty = 0;
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
-    const int cnt = src ? src_cnt : c.gnum;
+    const int cnt = src ? src_cnt : g_ws[c.wave].gnum;
+    const bool has_copy = g_ws[c.wave].has_copy != 0;
+    const uint32_t cur_id = g_ws[c.wave].cur_id;
     for (int k2 = c.lane; k2 < cnt; k2 += 64) {
-        const uint32_t pkx = src ? src[k2] : (c.has_copy ? c.gcopy[k2] : lget(c, k2));
+        const uint32_t pkx = src ? src[k2] : (has_copy ? c.gcopy[k2] : lget(c, k2));
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         const size_t q = (size_t)y * w + x;
-        if (src || c.stamp[q] == c.cur_id) {      // curMap == 1 only (src: a stashed list holds exactly those)
-            c.state[q] = val;
+        if (src || c.stamp[q] == cur_id) {        // curMap == 1 only (src: a stashed list holds exactly those)
+            const uint32_t old = c.pw[q];
+            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; }
+            else c.pw[q] = (old & ~3u) | kPwRejected;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
     }
@@ -1109,15 +1021,16 @@ __device__ __forceinline__ void mark_region(RCtx& c, uint32_t val, const uint32_
         x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
         x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
     }
-    bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
-    STAT(ST_TMARK, (long long)__builtin_amdgcn_s_memtime() - t0);
+    DSTAT(ST_TMARK, NOW() - t0);
+    Box bx; bx.x0 = x0; bx.y0 = y0; bx.x1 = x1; bx.y1 = y1;
+    return bx;
 }
 
-// bounding box of the pixels currently in the region list
-__device__ __forceinline__ void list_bbox(const RCtx& c, int num, int& bx0, int& by0, int& bx1, int& by1) {
-    int x0 = bx0, y0 = by0, x1 = bx1, y1 = by1;
+// bounding box of `in` and the first num pixels of the region list (of the grow-order copy when from_copy)
+__device__ __noinline__ Box list_bbox(RCtx c, int num, Box in, bool from_copy) {
+    int x0 = in.x0, y0 = in.y0, x1 = in.x1, y1 = in.y1;
     for (int k2 = c.lane; k2 < num; k2 += 64) {
-        const uint32_t pkx = lget(c, k2);
+        const uint32_t pkx = from_copy ? c.gcopy[k2] : lget(c, k2);
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
     }
@@ -1125,18 +1038,19 @@ __device__ __forceinline__ void list_bbox(const RCtx& c, int num, int& bx0, int&
         x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
         x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
     }
-    bx0 = x0; by0 = y0; bx1 = x1; by1 = y1;
+    Box bx; bx.x0 = x0; bx.y0 = y0; bx.x1 = x1; bx.y1 = y1;
+    return bx;
 }
 
 __device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Commit ring: one record per seed in flight (index = seed number & (RW-1)).
-//   R_EMPTY  not evaluated yet, or evaluated with a result that marks usedMap ("heavy": its owner keeps it
-//            in registers and commits it itself when the cursor reaches it)
+//   R_EMPTY  not evaluated yet, or evaluated with a result that marks usedMap ("heavy": stashed in one of its owner's
+//            slots; the owner commits it itself when the cursor reaches it)
 //   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
 //   R_LIGHT  evaluated, no marks to make (small region :228 or refine failed :237); whoever advances the
-//            cursor checks that no line accepted since the record's snapshot touches its box
+//            cursor checks that no line accepted since the record's snapshot touches what it examined
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
 //   R_BUSY   being re-evaluated at the cursor
 enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4 };
@@ -1146,22 +1060,13 @@ struct Ring {
     int state[RW];
     int snap[RW];
     short box[RW][4];
-    uint32_t lref[RW];   // list slot of the region ((wave * NB + buf) * NG + slot), ~0u: no lists kept (box check only)
+    uint32_t lref[RW];   // list slot of the region (wave * NS + slot), ~0u: no lists kept (box check only)
     uint32_t lcnt[RW];   // n1 | n2 << 16: sizes of the two lists in the slot (first grow, Refiner's regrow)
 };
 
-__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base, uint32_t id_base16) {
-    __shared__ uint32_t lst[NW][LCAP];
-    __shared__ uint16_t wl0[NW][LCAP], wl1[NW][LCAP];
-    __shared__ double t_deg[NW][NSLOT * 64], t_sn[NW][NSLOT * 64], t_cs[NW][NSLOT * 64];
-    __shared__ uint32_t t_st[NW][NSLOT * 64];
-    __shared__ int t_tag[NW][NSLOT];
-    __shared__ int s_incl[NW][64], s_lo[NW][64], s_x[NW][64];
-    __shared__ unsigned long long s_stat[NW][ST_COUNT];
-    __shared__ uint32_t g_ring[NW][NG * 64];             // tails of the 8 group-mode region lists of a wave
+__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
-    __shared__ int s_q[NW][2][NB];                       // in-flight blocks of a wave: first seed, accept epoch at fetch
     __shared__ Ring rg;
 
     const size_t img = blockIdx.x;
@@ -1170,22 +1075,22 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     const size_t npx = (size_t)g.npx;
 
     RCtx c;
-    c.w = w; c.h = h; c.lane = lane;
-    c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.state = b.state + img * npx;
-    c.sn = b.sn + img * npx; c.cs = b.cs + img * npx;
+    c.w = w; c.h = h; c.lane = lane; c.wave = wave;
+    c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
+    c.sc = b.sc + img * npx;
     c.stamp = b.stamps + (img * NW + wave) * npx;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
-    c.meta = reinterpret_cast<float2*>(b.wmeta) + (img * NW + wave) * (size_t)b.mcap; c.mcap = b.mcap;
-    c.lst = lst[wave]; c.wl0 = wl0[wave]; c.wl1 = wl1[wave];
-    c.t_st = t_st[wave]; c.t_deg = t_deg[wave]; c.t_sn = t_sn[wave]; c.t_cs = t_cs[wave]; c.t_tag = t_tag[wave];
-    c.s_incl = s_incl[wave]; c.s_lo = s_lo[wave]; c.s_x = s_x[wave];
-    c.tilesX = (w + 7) >> 3; c.dirty = false;
-    c.cur_id = id_base; c.gnum = 0; c.has_copy = false;
+    c.meta = b.wmeta + (img * NW + wave) * (size_t)b.mcap; c.mcap = b.mcap;
+    c.tilesX = (w + 7) >> 3; c.id_base = id_base;
+    if (lane == 0) {
+        WState& ws = g_ws[wave];
+        ws.cur_id = id_base; ws.gnum = 0; ws.has_copy = 0; ws.dirty = 0; ws.cache_epoch = -1; ws.members_cached = 0;
+        ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
+    }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
-    c.stat = s_stat[wave];
-    if (lane < ST_COUNT) c.stat[lane] = 0ull;
+    if (lane < ST_COUNT) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
-    if (lane < NSLOT) c.t_tag[lane] = -1;
+    if (lane < NT) g_ttag[c.wave][lane] = -1;
     for (int j = threadIdx.x; j < RW; j += 64 * NW) rg.state[j] = R_EMPTY;
 
     const uint32_t* ord = b.ord + img * npx;
@@ -1202,7 +1107,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int base = 0; base < nb; base += 64) {
             const int idx = base + lane;
-            const bool ok = idx < nb && (c.state[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
+            const bool ok = idx < nb && (c.pw[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
             const unsigned long long m = __ballot(ok);
             if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
             cnt += __builtin_popcountll(m);
@@ -1238,7 +1143,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     };
     // True if a pixel examined by a region (a member or one of its 8 neighbours) was banned by a line accepted in epoch
     // >= snap: only then can the region's evaluation differ from what it would be now (it read usedMap only as
-    // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 above the usedMap bits.
+    // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 in epochmap.
     auto examined_hit = [&](const uint32_t* lp, int cnt, int snap) -> bool {
         bool hit = false;
         for (int base = 0; base < cnt; base += 64) {
@@ -1250,8 +1155,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 for (int t9 = 0; t9 < 9; t9++) {
                     const int xx = x + t9 % 3 - 1, yy = y + t9 / 3 - 1;
                     if (xx >= 0 && yy >= 0 && xx < w && yy < h) {
-                        const uint32_t sw = c.state[(size_t)yy * w + xx];
-                        if ((sw & 3u) == 1u && (int)(sw >> 2) > snap) hit = true;
+                        const size_t q = (size_t)yy * w + xx;
+                        if ((c.pw[q] & 3u) == kPwLine && (int)c.epochmap[q] > snap) hit = true;
                     }
                 }
             }
@@ -1280,7 +1185,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     bool conflict = true;
                     if (lr != ~0u) {                       // the lists are still in their slot: look at the pixels themselves
                         wg_fence();
-                        conflict = examined_hit(b.glist + (img * (size_t)(NW * NB * NG) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
+                        conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
                     }
                     if (conflict) {
                         if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
@@ -1288,7 +1193,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     }
                 }
                 bool used_now = false;
-                if (trace) used_now = (c.state[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
+                if (trace) used_now = (c.pw[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
                 if (trace && !used_now) {
                     const int no = rnum[(f & (RW - 1)) * 2 + 1];
                     write_trace(f, rnum[(f & (RW - 1)) * 2], no >> 2, no & 3, 0.0);
@@ -1301,158 +1206,78 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (lane == 0) lds_st(&s_lock, 0);
     };
 
-    // group-mode storage of this wave's 8 groups (lane -> group lane>>3)
-    const int grp = lane >> 3;
-    uint32_t* const wave_glist = b.glist + (img * NW + wave) * (size_t)NB * NG * b.gcap;   // [NB][NG][gcap]
-    uint32_t* my_gwl = b.gwl + ((img * NW + wave) * NG + grp) * 2 * (size_t)b.gcap;
-    uint16_t* my_gstamp = b.gstamp + ((img * NW + wave) * NG + grp) * npx;
-    uint32_t gid_local = 0;                                // grows of this group in this run (16-bit stamp = id_base16 + it)
-
+    // Result slots of this wave: slot s holds the lists of the speculative result of seed slot_k (lane s of slot_k_l);
+    // it is free again once the cursor has passed that seed.  Results that mark usedMap ("heavy") are stashed -- record
+    // in pend[], pixels to mark in the slot -- and committed by this wave when the cursor reaches them.
+    uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
+    double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
+    int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
+    unsigned stash_mask = 0;                               // slots holding a stashed result
     int forced_k = -1;                                     // seed to (re)evaluate non-speculatively at the cursor
-    int blk_k0 = -NG, blk_g = NG, blk_snap = 0;            // current block of 8 consecutive seeds, next group to hand over
-    G8 blk;                                                // per-lane results of the block (group = lane>>3)
-    blk.n = 0; blk.sinS = 0; blk.cosS = 0; blk.bx0 = blk.by0 = 0; blk.bx1 = blk.by1 = -1;
-    bool blk_skip = true;
-    // Results that mark usedMap ("heavy") are stashed -- record in pend[], pixel list in the seed's glist slot of the
-    // block's buffer -- and the wave carries on: with the rest of its block, then with up to NB - 1 further blocks.
-    // Stashed results are committed in seed order as the cursor reaches them (the oldest block of the wave first).
-    int q_head = 0, q_cnt = 0, cur_buf = 0;                // ring of NB block buffers: oldest, blocks in flight, newest
-    unsigned pend32 = 0;                                   // byte i = slots of buffer i holding a stashed result
-    int* const qk = s_q[wave][0];
-    int* const qs = s_q[wave][1];
-    double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NB * NG * 24;
     const unsigned long long ltm = (1ull << lane) - 1ull;
-    long long tl = (long long)__builtin_amdgcn_s_memtime();
+    [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
-#define LT(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); STAT((i), t_ - tl); tl = t_; } while (0)
+#define LT(i) do { const long long t_ = NOW(); DSTAT((i), t_ - tl); tl = t_; } while (0)
     while (true) {
         // ---- choose the next job ----
-        int k;
-        bool spec, from_group = false, from_stash = false;
+        int k, slot = 0;
+        bool spec, from_stash = false;
         int epoch_snap;
-        int st_buf = 0, st_k0 = 0;                         // buffer / first seed of the block a stashed result belongs to
         LT(ST_TSELECT);
-        // retire blocks whose results are all handed over and committed
-        while (q_cnt > 0 && ((pend32 >> (8 * q_head)) & 0xffu) == 0u && (q_cnt > 1 || blk_g >= NG)) {
-            q_head = (q_head + 1) % NB; q_cnt--;
+        const int f = lds_ld(&s_commit);
+        int kp = -1, kp_slot = 0;                          // earliest stashed result of this wave
+        if (stash_mask) {
+            const int v = (lane < NS && ((stash_mask >> lane) & 1u)) ? slot_k_l : 0x7fffffff;
+            int mv = v;
+            for (int off = 1; off < NS; off <<= 1) mv = min(mv, __shfl_xor(mv, off));
+            kp = __builtin_amdgcn_readfirstlane(mv);
+            kp_slot = __builtin_ctzll(__ballot(lane < NS && v == kp));
         }
-        int kp = -1;                                       // earliest stashed result of this wave
-        if (q_cnt > 0) {
-            const unsigned m = (pend32 >> (8 * q_head)) & 0xffu;
-            if (m) { st_buf = q_head; st_k0 = qk[q_head]; kp = st_k0 + __builtin_ctz(m); }
-        }
-        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; epoch_snap = lds_ld(&s_epoch); }
+        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; }
         else {
             // a record waiting to be redone at the cursor has priority
-            const int f = lds_ld(&s_commit);
             int won = 0;
             if (f < nseeds && lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) {
                 if (lane == 0) won = atomicCAS(&rg.state[f & (RW - 1)], R_REDO, R_BUSY) == R_REDO ? 1 : 0;
                 won = __builtin_amdgcn_readfirstlane(won);
             }
-            if (won) { k = f; spec = false; epoch_snap = lds_ld(&s_epoch); }
+            if (won) { k = f; spec = false; }
             else if (kp == f) {
                 // ---- the cursor is at a stashed result of this wave: commit it ----
-                k = kp;
-                from_stash = true; spec = true; epoch_snap = qs[st_buf];
-            }
-            else if (q_cnt > 0 && blk_g < NG) {
-                // ---- hand over the next result of the current block ----
-                const int gq = blk_g++;
-                k = blk_k0 + gq;
-                if (k >= nseeds) { blk_g = NG; continue; }
-                const int src = gq * 8;
-                const bool gskip = __builtin_amdgcn_readlane((int)blk_skip, src) != 0;
-                const int gn = __builtin_amdgcn_readlane(blk.n, src);
-                if (gskip) {
-                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
-                    if (gq == NG - 1) advance();
-                    continue;
-                }
-                if (gn >= 0 && gn < g.regThre) {           // small region (:228): nothing to evaluate, nothing to mark
-                    // cross-lane reads stay in uniform control flow (values of inactive lanes are not defined inside a branch)
-                    const int qx0 = __builtin_amdgcn_readlane(blk.bx0, src), qy0 = __builtin_amdgcn_readlane(blk.by0, src);
-                    const int qx1 = __builtin_amdgcn_readlane(blk.bx1, src), qy1 = __builtin_amdgcn_readlane(blk.by1, src);
-                    if (lane == 0) {
-                        const int r = k & (RW - 1);
-                        rg.snap[r] = blk_snap;
-                        rg.box[r][0] = (short)(qx0 - 1);
-                        rg.box[r][1] = (short)(qy0 - 1);
-                        rg.box[r][2] = (short)(qx1 + 1);
-                        rg.box[r][3] = (short)(qy1 + 1);
-                        rg.lref[r] = ~0u; rg.lcnt[r] = 0u;
-                        if (trace) { rnum[r * 2] = gn; rnum[r * 2 + 1] = (gn << 2) | 0; }
-                        lds_st(&rg.state[r], R_LIGHT);
-                    }
-                    if (gq == NG - 1) advance();
-                    continue;
-                }
-                spec = true;
-                epoch_snap = blk_snap;
-                from_group = gn >= 0;                      // gn < 0: list overflow in group mode -> plain grow() below
-            } else if (q_cnt < NB && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - NW * NG) {
-                // ---- fetch a block of 8 consecutive seeds and grow them together ----
-                if (NB == 1 && blk_k0 >= 0 && f < blk_k0 + NG) {
-                    // records of the previous block are still ahead of the cursor and its list slots are about to be reused:
-                    // withdraw their lists (under the cursor lock), their validation falls back to the bounding box
-                    while (true) {
-                        int got = 0;
-                        if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0 ? 1 : 0;
-                        if (__builtin_amdgcn_readfirstlane(got)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (lane < NG && blk_k0 + lane < nseeds) rg.lref[(blk_k0 + lane) & (RW - 1)] = ~0u;
-                    wg_fence();
-                    if (lane == 0) lds_st(&s_lock, 0);
-                }
-                int k0 = 0;
-                if (lane == 0) k0 = atomicAdd(&s_next, NG);
-                k0 = __builtin_amdgcn_readfirstlane(k0);
-                if (k0 >= nseeds) continue;
-                cur_buf = (q_head + q_cnt) % NB; q_cnt++;
-                blk_k0 = k0; blk_g = 0;
-                blk_snap = lds_ld(&s_epoch);               // before anything of usedMap is read for these seeds
-                if (lane == 0) { qk[cur_buf] = k0; qs[cur_buf] = blk_snap; }
-                wg_fence();
-                const int kg = k0 + grp;
-                bool gact = kg < nseeds;
-                int gsx = 0, gsy = 0;
-                if (gact) {
-                    const uint32_t ppg = ord[seedidx[kg]];
-                    gsx = (int)(ppg % (uint32_t)w); gsy = (int)(ppg / (uint32_t)w);
-                    if ((c.state[ppg] & 3u) != 0u) gact = false;          // monotone: once used, always used (:222)
-                }
-                blk_skip = !gact;
-                if (gid_local >= 2047u) {                  // 16-bit stamp range of this run exhausted: plain grow() for the rest
-                    blk.n = -1;
-                } else {
-                    gid_local++;
-                    G8Ctx gc;
-                    gc.w = w; gc.h = h; gc.lane = lane; gc.deg = c.deg; gc.sn = c.sn; gc.cs = c.cs; gc.state = c.state; gc.stat = c.stat;
-                    blk = grow8(gc, gact, gsx, gsy, wave_glist + ((size_t)cur_buf * NG + grp) * b.gcap, my_gwl, my_gstamp,
-                                (uint16_t)(id_base16 + gid_local), g_ring[wave], b.gcap, g.degThre);
-                }
-                LT(ST_TGROUP);
-                continue;
-            } else if (kp >= 0) {
-                // ---- nothing else to do: wait for the turn of the earliest stashed result ----
-                const long long tw0 = (long long)__builtin_amdgcn_s_memtime();
-                while (true) {
-                    advance();
-                    const int f2 = lds_ld(&s_commit);
-                    if (f2 == kp) break;
-                    if (lds_ld(&rg.state[f2 & (RW - 1)]) == R_REDO) break;   // somebody has to redo f2 (top of the loop)
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                tl = (long long)__builtin_amdgcn_s_memtime();
-                STAT(ST_WAIT, tl - tw0);
-                continue;
+                k = kp; slot = kp_slot;
+                from_stash = true; spec = true;
             } else {
-                advance();
-                if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
-                __builtin_amdgcn_s_sleep(8);               // nothing left to hand out, or the run-ahead window is full
-                LT(ST_TIDLE);
-                continue;
+                // a free slot (the cursor has passed its seed) and a seed left to hand out?
+                const unsigned long long freem = __ballot(lane < NS && slot_k_l < f);
+                bool took = false;
+                if (freem && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - 2 * NW) {
+                    int k0 = 0;
+                    if (lane == 0) k0 = atomicAdd(&s_next, 1);
+                    k0 = __builtin_amdgcn_readfirstlane(k0);
+                    if (k0 < nseeds) { k = k0; slot = __builtin_ctzll(freem); spec = true; took = true; }
+                }
+                if (!took) {
+                    if (kp >= 0) {
+                        // ---- nothing else to do: wait for the turn of the earliest stashed result ----
+                        [[maybe_unused]] const long long tw0 = NOW();
+                        while (true) {
+                            advance();
+                            const int f2 = lds_ld(&s_commit);
+                            if (f2 == kp) break;
+                            if (f2 < nseeds && lds_ld(&rg.state[f2 & (RW - 1)]) == R_REDO) break;   // somebody has to redo f2 (top of the loop)
+                            if (__ballot(lane < NS && slot_k_l < f2) && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f2 < RW - 2 * NW) break;   // a slot came free
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        tl = NOW();
+                        DSTAT(ST_WAIT, tl - tw0);
+                        continue;
+                    }
+                    advance();
+                    if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
+                    __builtin_amdgcn_s_sleep(2);           // nothing left to hand out, or every slot waits for the cursor
+                    LT(ST_TIDLE);
+                    continue;
+                }
             }
         }
         const int oidx = (int)seedidx[k];
@@ -1461,7 +1286,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 
         int outcome = 0, num = 0, num0 = 0;
         double logNFA = 0;
-        Rec rec;
+        double pv = 0;                                     // lane j < 12: field j of the result's rectangle (structRec order)
+        int rec_pk = 0;
         bool skip = false;
         const uint32_t* m_src = nullptr;                   // stashed pixel list to mark at commit (else the wave's own list)
         int m_cnt = 0;
@@ -1469,130 +1295,119 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         int st_n1 = -1, st_n2 = 0;                         // stashed result: sizes of the lists kept in its slot (-1: none)
         const uint32_t* st_list = nullptr;
         if (from_stash) {
-            const int slot = k - st_k0;
-            pend32 &= ~(1u << (8 * st_buf + slot));
+            stash_mask &= ~(1u << slot);
             wg_fence();
-            const double pv = wave_pend[(st_buf * NG + slot) * 24 + (lane < 24 ? lane : 0)];
-            rec.x1 = rl(pv, 0); rec.y1 = rl(pv, 1); rec.x2 = rl(pv, 2); rec.y2 = rl(pv, 3); rec.wid = rl(pv, 4); rec.cX = rl(pv, 5);
-            rec.cY = rl(pv, 6); rec.deg = rl(pv, 7); rec.dx = rl(pv, 8); rec.dy = rl(pv, 9); rec.p = rl(pv, 10); rec.prec = rl(pv, 11);
+            pv = wave_pend[slot * 24 + (lane < 24 ? lane : 0)];
             logNFA = rl(pv, 12);
-            rec.pk = (int)rl(pv, 13); outcome = (int)rl(pv, 14); num0 = (int)rl(pv, 15); num = (int)rl(pv, 16); m_cnt = (int)rl(pv, 17);
+            rec_pk = (int)rl(pv, 13); outcome = (int)rl(pv, 14); num0 = (int)rl(pv, 15); num = (int)rl(pv, 16); m_cnt = (int)rl(pv, 17);
             x0 = (int)rl(pv, 18); y0 = (int)rl(pv, 19); x1 = (int)rl(pv, 20); y1 = (int)rl(pv, 21);
+            epoch_snap = (int)rl(pv, 23);
             {
                 const long long pk3 = (long long)rl(pv, 22);
                 st_n1 = (int)(pk3 % 32768ll) - 1; st_n2 = (int)((pk3 / 32768ll) % 32768ll);
-                st_list = wave_glist + ((size_t)st_buf * NG + slot) * b.gcap;
+                st_list = wave_slist + (size_t)slot * b.gcap;
                 m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
             }
         } else {
         // ---- evaluate ----
-        if (!from_group) { wg_fence(); }
-        invalidate_tiles(c);
-        skip = from_group ? false : (c.state[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
+        if (lane == slot && spec) slot_k_l = k;            // the slot is taken until the cursor has passed seed k
+        epoch_snap = lds_ld(&s_epoch);                     // before anything of usedMap is read for this seed
+        wg_fence();
+        if (!spec || epoch_snap != g_ws[c.wave].cache_epoch) {    // tiles fetched before the last accept may miss its bans
+            invalidate_tiles(c);
+            if (lane == 0) g_ws[c.wave].cache_epoch = epoch_snap;
+        }
+        skip = (c.pw[pp] & 3u) != 0u;                      // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
-        uint32_t* const gl0 = wave_glist + ((size_t)cur_buf * NG + (spec ? k - blk_k0 : 0)) * b.gcap;
+        uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
         int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
         bool regrown = false;
         if (!skip) {
             // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
-            // global tolerance (or takes the region grown in group mode), pass 1 (only when the rectangle is too
-            // sparse, :829) regrows with the tolerance re-estimated by Refiner (:833-857).
+            // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
+            // re-estimated by Refiner (:833-857).
             const double seedDeg = c.deg[pp];
-            double tol = g.degThre, regdeg = seedDeg, gs, gc;
+            double tol = g.degThre, regdeg = seedDeg;
             bool done = false;
             for (int pass = 0; pass < 2 && !done; pass++) {
-                if (pass == 0 && from_group) {
-                    // the region of seed k was grown by group (k - blk_k0): bring its list into this wave's list storage
-                    const int src = (k - blk_k0) * 8;
-                    num = __builtin_amdgcn_readlane(blk.n, src);
-                    gs = rl(blk.sinS, src); gc = rl(blk.cosS, src);
-                    const uint32_t* gl = wave_glist + ((size_t)cur_buf * NG + (k - blk_k0)) * b.gcap;
-                    for (int k2 = lane; k2 < num && k2 < LCAP; k2 += 64) c.lst[k2] = gl[k2];
-                    for (int k2 = LCAP + lane; k2 < num; k2 += 64) c.spill[k2 - LCAP] = gl[k2];
-                    c.gnum = num; c.has_copy = false;
+                num = grow(c, sx, sy, seedDeg, tol);                                  // :225 / :857
+                if (pass == 0 && spec && num <= b.gcap) {              // keep the first list for the validation at the cursor
+                    for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
                     n1 = num;
-                    wg_fence();
-                } else {
-                    const long long tg0 = (long long)__builtin_amdgcn_s_memtime();
-                    grow(c, sx, sy, seedDeg, tol, num, gs, gc);                       // :225 / :857
-                    if (pass == 0) { STAT(ST_THANDED, (long long)__builtin_amdgcn_s_memtime() - tg0); STAT(ST_NHANDED, 1); STAT(ST_PXHANDED, num); }
-                    if (pass == 0 && spec && num <= b.gcap) {          // keep the first list for the validation at the cursor
-                        for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
-                        n1 = num;
-                    }
-                    if (pass == 1) regrown = true;
-
                 }
+                if (pass == 1) regrown = true;
                 if (pass == 0) {
                     num0 = num;
                     if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
                 } else if (num < 2) { outcome = 1; done = true; break; }              // :861
-                regdeg = num > 1 ? atan2_g(gs, gc) : seedDeg;                         // reg.deg (:547, :581)
-                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre, rec);            // :232 / :866 (p, prec still the defaults)
-                const double den = rec_density(num, rec);
+                if (num > 1) { exact_sums(c, num); regdeg = atan2_g(g_ws[c.wave].ex_sin, g_ws[c.wave].ex_cos); }   // reg.deg (:547, :581)
+                else regdeg = seedDeg;
+                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre);                 // :232 / :866 (p, prec still the defaults)
+                const double den = rec_density(num, g_ws[c.wave].rec);
                 if (pass == 0) {
                     if (den >= g.denThre) break;                                      // :829 dense enough
-                    if (spec) list_bbox(c, num, fx0, fy0, fx1, fy1);                  // the regrow replaces this list
-                    tol = refine_tol(c, sx, sy, num, rec, seedDeg);                   // :833-855
+                    if (spec) {                                                       // the regrow replaces this list
+                        Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
+                        fb = list_bbox(c, num, fb, false);
+                        fx0 = fb.x0; fy0 = fb.y0; fx1 = fb.x1; fy1 = fb.y1;
+                    }
+                    tol = refine_tol(c, sx, sy, num, seedDeg);                        // :833-855
                 } else if (den < g.denThre) {                                         // :869-877
-                    int copied = 0;
-                    const bool ok = radius_reduce(c, sx, sy, &num, regdeg, &rec, g.denThre, &copied);
-                    c.has_copy = copied != 0;                // lst was reordered: gcopy holds the grow-order list
-                    if (!ok) { outcome = 1; done = true; }
+                    const int r = radius_reduce(c, sx, sy, num, regdeg, g.denThre);   // (lst reordered: gcopy holds the grow-order list)
+                    if (r < 0) { num = -r - 1; outcome = 1; done = true; }
+                    else num = r;
                 }
             }
             if (!done) {
-                logNFA = improve(c, rec);                                             // :240
+                logNFA = improve(c);                                                  // :240
                 outcome = logNFA <= 0 ? 2 : 3;                                        // :242
+                pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[c.wave].rec)[lane] : 0.0;
+                rec_pk = g_ws[c.wave].rec.pk;
             }
         }
+        const int gnum = g_ws[c.wave].gnum;                       // size of the last grow (grow order)
+        const bool has_copy = g_ws[c.wave].has_copy != 0;
 
         // ---- hand the result over ----
         LT(ST_TEVAL);
         if (spec) {
             if (skip) {
+                if (lane == slot) slot_k_l = -1;           // nothing kept in the slot
                 if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
                 advance();
                 continue;
             }
             // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
-            x0 = fx0; y0 = fy0; x1 = fx1; y1 = fy1;
-            if (c.has_copy) {                              // RegionRadiusReducer reordered/shrunk lst: use the grow-order copy
-                for (int k2 = lane; k2 < c.gnum; k2 += 64) {
-                    const uint32_t pkx = c.gcopy[k2];
-                    const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
-                    x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
-                }
-                for (int off = 32; off >= 1; off >>= 1) {
-                    x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
-                    x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
-                }
-            } else list_bbox(c, c.gnum, x0, y0, x1, y1);
-            x0 -= 1; y0 -= 1; x1 += 1; y1 += 1;
+            {                                              // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
+                Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
+                fb = list_bbox(c, gnum, fb, has_copy);
+                x0 = fb.x0 - 1; y0 = fb.y0 - 1; x1 = fb.x1 + 1; y1 = fb.y1 + 1;
+            }
             bool precise = n1 >= 0;
             int n2 = 0;
             if (regrown) {                                 // keep Refiner's regrow (in grow order, before any reduction) behind the first list
-                if (precise && n1 + c.gnum <= b.gcap) {
-                    for (int k2 = lane; k2 < c.gnum; k2 += 64) gl0[n1 + k2] = c.has_copy ? c.gcopy[k2] : lget(c, k2);
-                    n2 = c.gnum;
+                if (precise && n1 + gnum <= b.gcap) {
+                    for (int k2 = lane; k2 < gnum; k2 += 64) gl0[n1 + k2] = has_copy ? c.gcopy[k2] : lget(c, k2);
+                    n2 = gnum;
                 } else precise = false;
             }
-            const int slot = k - blk_k0;
+            if (n1 > 32767 || n2 > 32767) precise = false; // (the sizes travel in 15-bit fields)
             if (outcome <= 1) {                            // nothing to mark: publish and move on
                 if (lane == 0) {
                     const int r = k & (RW - 1);
                     rg.snap[r] = epoch_snap;
                     rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
-                    rg.lref[r] = precise ? (uint32_t)((wave * NB + cur_buf) * NG + slot) : ~0u;
+                    rg.lref[r] = precise ? (uint32_t)(wave * NS + slot) : ~0u;
                     rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
                     if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
-                    lds_st(&rg.state[r], R_LIGHT);
                 }
+                wg_fence();                                // the lists are in the slot before the record says so
+                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
                 advance();
                 continue;
             }
-            // marks to make: stash the result (record in pend[], the pixels to mark in the list slot) and carry on with the block
+            // marks to make: stash the result (record in pend[], the pixels to mark in the list slot) and carry on
             int m_off = 0, mcnt = num;                     // not regrown: the first list is exactly the region
             if (!regrown) {
                 if (!precise) {                            // (larger than a list slot) evaluate again at the cursor
@@ -1601,50 +1416,53 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     advance();
                     continue;
                 }
-            } else if (precise && !c.has_copy) { m_off = n1; mcnt = n2; }      // the regrow as it is
+            } else if (precise && !has_copy) { m_off = n1; mcnt = n2; }        // the regrow as it is
             else {
                 m_off = precise ? n1 + n2 : 0;
-                if (m_off + c.gnum > b.gcap) { precise = false; m_off = 0; }
-                if (c.gnum > b.gcap) {
+                if (m_off + gnum > b.gcap) { precise = false; m_off = 0; }
+                if (gnum > b.gcap) {
                     if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
                     STAT(ST_REDO, 1);
                     advance();
                     continue;
                 }
                 wg_fence();                                // the stamps written by grow() must have landed
-                c.dirty = false;
+                if (lane == 0) g_ws[c.wave].dirty = 0;
+                const uint32_t cur_id = g_ws[c.wave].cur_id;
                 mcnt = 0;
-                for (int base = 0; base < c.gnum; base += 64) {
+                for (int base = 0; base < gnum; base += 64) {
                     const int k2 = base + lane;
                     uint32_t pkx = 0;
                     bool keep = false;
-                    if (k2 < c.gnum) {
-                        pkx = c.has_copy ? c.gcopy[k2] : lget(c, k2);
-                        keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == c.cur_id;   // curMap == 1 only
+                    if (k2 < gnum) {
+                        pkx = has_copy ? c.gcopy[k2] : lget(c, k2);
+                        keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == cur_id;   // curMap == 1 only
                     }
                     const unsigned long long km = __ballot(keep);
                     if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
                     mcnt += __builtin_popcountll(km);
                 }
             }
+            if (lane < 12) wave_pend[slot * 24 + lane] = pv;
             if (lane == 0) {
-                double* P = wave_pend + (cur_buf * NG + slot) * 24;
-                P[0] = rec.x1; P[1] = rec.y1; P[2] = rec.x2; P[3] = rec.y2; P[4] = rec.wid; P[5] = rec.cX; P[6] = rec.cY;
-                P[7] = rec.deg; P[8] = rec.dx; P[9] = rec.dy; P[10] = rec.p; P[11] = rec.prec; P[12] = logNFA;
-                P[13] = (double)rec.pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
+                double* P = wave_pend + slot * 24;
+                P[12] = logNFA;
+                P[13] = (double)rec_pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
                 P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
                 P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
+                P[23] = (double)epoch_snap;
             }
             wg_fence();
-            pend32 |= 1u << (8 * cur_buf + slot);
+            stash_mask |= 1u << slot;
             continue;
         }
         }   // !from_stash
 
+        LT(ST_TSELECT);
         if (spec) {
             // ---- a stashed result at the cursor (k == s_commit): is it still what the sequential run would get? ----
             wg_fence();
-            bool bad = (c.state[pp] & 3u) != 0u;           // an earlier seed marked the pixel meanwhile
+            bool bad = (c.pw[pp] & 3u) != 0u;              // an earlier seed marked the pixel meanwhile
             if (bad) {
                 STAT(ST_DISCARD, 1);
                 if (lane == 0) { lds_st(&s_commit, k + 1); }
@@ -1665,36 +1483,30 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         // ---- commit at the cursor (k == s_commit, nobody else can commit) ----
         if (!skip) {
             write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
-            int bx0, by0, bx1, by1;
             if (outcome == 2) {                                                      // :242-250
-                mark_region(c, 2u, m_src, m_cnt, bx0, by0, bx1, by1);
+                (void)mark_region(c, 0u, m_src, m_cnt);
             } else if (outcome == 3) {
                 const int li = s_lines;
-                if (li < b.max_lines && lane == 0) {
-                    double* rr = recs + (size_t)li * 12;
-                    rr[0] = rec.x1; rr[1] = rec.y1; rr[2] = rec.x2; rr[3] = rec.y2; rr[4] = rec.wid; rr[5] = rec.cX;
-                    rr[6] = rec.cY; rr[7] = rec.deg; rr[8] = rec.dx; rr[9] = rec.dy; rr[10] = rec.p; rr[11] = rec.prec;
-                    double x1 = rec.x1, y1 = rec.y1, x2 = rec.x2, y2 = rec.y2;
-                    if (g.sca != 1) {                                                // :252-258
-                        x1 = (x1 - 1.0) / g.sca + 1; y1 = (y1 - 1.0) / g.sca + 1;
-                        x2 = (x2 - 1.0) / g.sca + 1; y2 = (y2 - 1.0) / g.sca + 1;
-                    }
-                    double* rs = recs_scaled + (size_t)li * 4;
-                    rs[0] = x1; rs[1] = y1; rs[2] = x2; rs[3] = y2;
+                if (li < b.max_lines) {
+                    if (lane < 12) recs[(size_t)li * 12 + lane] = pv;                // structRec as accepted
+                    if (lane < 4) recs_scaled[(size_t)li * 4 + lane] = g.sca != 1 ? (pv - 1.0) / g.sca + 1 : pv;   // x1 y1 x2 y2, :252-258
                 }
-                mark_region(c, 1u | ((uint32_t)(lds_ld(&s_epoch) + 1) << 2), m_src, m_cnt, bx0, by0, bx1, by1);   // :259-265 (+ the line's epoch)
+                const Box mb = mark_region(c, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
                 wg_fence();                               // the marks must be visible before the epoch moves
                 if (lane == 0) {
                     const int ep = s_epoch;
                     short* r = s_ring[ep & (RING - 1)];
-                    r[0] = (short)bx0; r[1] = (short)by0; r[2] = (short)bx1; r[3] = (short)by1;
+                    r[0] = (short)mb.x0; r[1] = (short)mb.y0; r[2] = (short)mb.x1; r[3] = (short)mb.y1;
                     s_lines = li + 1;
                     lds_st(&s_epoch, ep + 1);
                 }
+                invalidate_tiles(c);                      // this wave's cached ban flags are stale now
+                if (lane == 0) g_ws[c.wave].cache_epoch = -1;
             }
         }
         wg_fence();                                       // marks + ring visible before the cursor moves
         if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
+        LT(ST_TCOMMIT);
     }
 
     __syncthreads();
@@ -1704,10 +1516,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     }
     if (b.stats) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 32);
-        if (lane == 0 && wave == 0) { c.stat[ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); c.stat[ST_SEEDS] = (unsigned long long)nseeds; }
+        if (lane == 0 && wave == 0) { g_stat[c.wave][ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][ST_SEEDS] = (unsigned long long)nseeds; }
         if (lane < ST_COUNT) {
-            if (lane == ST_MAXREG) atomicMax(&st[lane], c.stat[lane]);
-            else atomicAdd(&st[lane], c.stat[lane]);
+            if (lane == ST_MAXREG) atomicMax(&st[lane], g_stat[c.wave][lane]);
+            else atomicAdd(&st[lane], g_stat[c.wave][lane]);
         }
     }
 }
@@ -1715,17 +1527,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 }  // namespace RVAR
 
 #if LSD_REGION_NW == 8
-void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
-    hipLaunchKernelGGL(w8::k_region, dim3(n), dim3(64 * w8::NW), 0, s, g, b, id_base, id_base16);
+void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
+    hipLaunchKernelGGL(w8::k_region, dim3(n), dim3(64 * w8::NW), 0, s, g, b, id_base);
 }
 // workspace is sized for the wider variant
-int region_groups() { return w8::NW * w8::NG; }
+int region_slots() { return w8::NS; }
 int region_waves() { return w8::NW; }
-int region_blocks() { return w8::NB; }
 int region_ring() { return w8::RW; }
 #else
-void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s) {
-    hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base, id_base16);
+void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
+    hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base);
 }
 #endif
 

@@ -29,15 +29,13 @@ struct lsd_ctx {
     int cap_max_lines = 0;
     bool cap_trace = false;
     // workspace
-    double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *sn = nullptr, *cs = nullptr, *recs = nullptr,
-           *recs_scaled = nullptr;
-    uint32_t *state = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
-    uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number
-    uint32_t run16 = 0;    // same for the 16-bit group stamps: (run16 << 11) + grow number, run16 in [1, 31]
-    uint32_t *glist = nullptr, *gwl = nullptr;
-    uint16_t* gstamp = nullptr;
+    double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
+    double2* sc = nullptr;
+    uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
+    uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number (a wave that uses up its 2^20 clears its stamps)
+    uint32_t* slist = nullptr;
     double* pend = nullptr;
-    float* wmeta = nullptr;
+    float4* wmeta = nullptr;
     int* rnum = nullptr;
     int mcap = 16384;
     int gcap = 16384;
@@ -81,6 +79,8 @@ struct lsd_ctx {
     int32_t* last_counts = nullptr;
     hipEvent_t ev[7]{};
     bool ev_valid = false;
+    hipEvent_t ev_done = nullptr;      // end of the last enqueue: a later enqueue on ANOTHER stream waits for it (shared workspace)
+    bool done_valid = false;
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -132,11 +132,13 @@ static int make_geom(const lsd_params* p, int cols, int rows, Geom* g) {
     if (!p || cols <= 0 || rows <= 0) return LSD_ERR_INVALID;
     if (!(p->sca > 0) || !(p->sig > 0) || !(p->angThre > 0) || p->pseBin < 1) return LSD_ERR_INVALID;
     if (p->pseBin > 1024) return LSD_ERR_UNSUPPORTED;
-    if (cols > 65535 || rows > 65535) return LSD_ERR_UNSUPPORTED;   // region lists pack (y<<16 | x)
+    if (cols > 65535 || rows > 65535) return LSD_ERR_UNSUPPORTED;
     g->W = cols; g->H = rows;
     g->w = cvt_x86(floor(cols * p->sca));                           // myLSD.cpp:132
     g->h = cvt_x86(floor(rows * p->sca));                           // :133
     if (g->w < 2 || g->h < 2) return LSD_ERR_INVALID;
+    // the region stage packs scaled coordinates as (y<<16 | x) and keeps bounding boxes (+-1 margin) in 16-bit signed fields
+    if (g->w > 32766 || g->h > 32766) return LSD_ERR_UNSUPPORTED;
     if ((long long)g->w * g->h > (1ll << 30)) return LSD_ERR_UNSUPPORTED;
     g->npx = g->w * g->h;
     g->sca = p->sca;
@@ -171,6 +173,7 @@ static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStre
         pr /= 2.0;                                                                          // :1085,:1149
     }
     HIPCHK(c, hipStreamSynchronize(s));
+    if (c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));     // kernels of an earlier enqueue may still read the tables
     HIPCHK(c, hipMemcpy(c->d_taps, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_ptab, pt, sizeof(pt), hipMemcpyHostToDevice));
     c->tab_params = *p;
@@ -201,18 +204,15 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, in
         HIPCHK(c, hipDeviceSynchronize());
         const size_t tot = nn * pp;
         HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
-        HIPCHK(c, re_alloc(&c->sn, tot)); HIPCHK(c, re_alloc(&c->cs, tot));
-        HIPCHK(c, re_alloc(&c->state, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
-        HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap * 2));
+        HIPCHK(c, re_alloc(&c->sc, tot));
+        HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
+        HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
         HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
         c->run_id = 0;
-        const size_t gs = ws * (size_t)(region_groups() / region_waves());      // group slots: 8 per wave slot
-        HIPCHK(c, re_alloc(&c->glist, gs * (size_t)region_blocks() * (size_t)c->gcap)); HIPCHK(c, re_alloc(&c->gwl, gs * 2 * (size_t)c->gcap));
-        HIPCHK(c, re_alloc(&c->gstamp, gs * pp));
-        HIPCHK(c, re_alloc(&c->pend, gs * (size_t)region_blocks() * 24));
-        HIPCHK(c, hipMemset(c->gstamp, 0, gs * pp * sizeof(uint16_t)));
-        c->run16 = 0;
+        const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
+        HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
+        HIPCHK(c, re_alloc(&c->pend, gs * 24));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
@@ -240,9 +240,9 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
     const int st = ensure_workspace_impl(c, n, npx, wh, max_lines, trace);
     if (st != LSD_OK) {
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
-        void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sn, (void**)&c->cs, (void**)&c->state,
+        void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->glist, (void**)&c->gwl, (void**)&c->gstamp, (void**)&c->pend,
+                         (void**)&c->seedidx, (void**)&c->slist, (void**)&c->pend,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
@@ -298,6 +298,7 @@ int lsd_create(lsd_ctx** out, int device) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LSD_ERR_HIP; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return LSD_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_HIP; }
     c->last_stream = c->stream;
     *out = c;
     return LSD_OK;
@@ -307,11 +308,12 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sn, c->cs, c->recs, c->recs_scaled, c->state, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->glist, c->gwl, c->gstamp, c->pend, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->slist, c->pend, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -359,13 +361,15 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     if (st != LSD_OK) return st;
     st = ensure_tables(c, p, g, s);
     if (st != LSD_OK) return st;
+    // the workspace is shared by every enqueue of this context: work queued on another stream must be over first
+    if (c->done_valid && c->last_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->ev_done, 0));
 
     Buffers b{};
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
-    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sn = c->sn; b.cs = c->cs; b.state = c->state; b.maxbits = c->maxbits; b.nb = c->nb;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
-    b.glist = c->glist; b.gwl = c->gwl; b.gstamp = c->gstamp; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
+    b.slist = c->slist; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
@@ -391,18 +395,16 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             c->run_id = 1;
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
-        if (++c->run16 >= 32u) {
-            HIPCHK(c, hipMemsetAsync(c->gstamp, 0, c->cap_ws * (size_t)(region_groups() / region_waves()) * c->cap_npx * sizeof(uint16_t), s));
-            c->run16 = 1;
-        }
         // 8 wavefronts per image take a whole CU each: worth it while the batch leaves CUs idle (<= one image per CU)
         const bool wide = waves_for(c, n) == 8;
-        if (wide) launch_region_w8(g, b, n, c->run_id << 20, c->run16 << 11, s);
-        else launch_region_w4(g, b, n, c->run_id << 20, c->run16 << 11, s);
+        if (wide) launch_region_w8(g, b, n, c->run_id << 20, s);
+        else launch_region_w4(g, b, n, c->run_id << 20, s);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     if (c->stop_after == 0) launch_lines(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipEventRecord(c->ev_done, s));
+    c->done_valid = true;
     HIPCHK(c, hipGetLastError());
     c->ev_valid = true;
     c->geom = g; c->last_n = n; c->last_max_lines = max_lines; c->last_counts = d_counts; c->last_stream = s;
@@ -517,7 +519,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
         case LSD_DBG_GAUSS: src = c->gauss + off; need = npx * 8; break;
         case LSD_DBG_MAG: src = c->mag + off; need = npx * 8; break;
         case LSD_DBG_DEG: src = c->deg + off; need = npx * 8; break;
-        case LSD_DBG_STATE: src = c->state + off; need = npx * 4; break;
+        case LSD_DBG_STATE: src = c->pw + off; need = npx * 4; break;
         case LSD_DBG_ORDER:
         case LSD_DBG_ORDER_VAL:
             HIPCHK(c, hipMemcpy(&nbv, c->nb + image, 4, hipMemcpyDeviceToHost));
@@ -542,6 +544,10 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
     }
     if (bytes < need) return LSD_ERR_INVALID;
     if (need) HIPCHK(c, hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    if (what == LSD_DBG_STATE) {                                   // packed pixel words -> usedMap values (lsd_internal.h)
+        uint32_t* o = static_cast<uint32_t*>(out);
+        for (size_t i = 0; i < npx; i++) o[i] = pw_used(o[i]);
+    }
     return LSD_OK;
 }
 
@@ -696,7 +702,7 @@ int lsd_debug_calibrate(lsd_ctx* c, size_t bytes) {
 }
 
 int lsd_debug_eval_math(lsd_ctx* c, int fn, const double* a, const double* b, double* out0, double* out1, size_t n) {
-    if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 2 || (fn == 1 && !b)) return LSD_ERR_INVALID;
+    if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 3 || (fn == 1 && !b)) return LSD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
     HIPCHK(c, hipMalloc(&da, n * 8)); HIPCHK(c, hipMalloc(&db, n * 8)); HIPCHK(c, hipMalloc(&d0, n * 8)); HIPCHK(c, hipMalloc(&d1, n * 8));

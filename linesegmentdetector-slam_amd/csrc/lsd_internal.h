@@ -28,6 +28,14 @@ struct Geom {
     double denThre;
 };
 
+// The packed pixel word pw[q] of the scaled image (written by K2, read by the region stage):
+//   bits 31..2  the level-line angle degMap[q] as fp32 with the two lowest mantissa bits cleared (|error| < 1e-6 rad)
+//   bits  1..0  usedMap code: 0 free, 1 banned by the gradient threshold (myLSD.cpp:165-166), 2 marked by a rejected
+//               region (usedMap == 2: growable, not seedable), 3 banned by an accepted line (usedMap == 1; the line's
+//               epoch is in epochmap[q], written before the code).  usedMap value = code == 3 ? 1 : code.
+constexpr uint32_t kPwFree = 0u, kPwStatic = 1u, kPwRejected = 2u, kPwLine = 3u;
+__host__ __device__ inline uint32_t pw_used(uint32_t w) { return (w & 3u) == 3u ? 1u : (w & 3u); }
+
 // Per-batch device buffers (image i lives at base + i*stride of each array).
 struct Buffers {
     const uint8_t* in;     // n x H x W (pitch W)
@@ -35,9 +43,9 @@ struct Buffers {
     double* gauss;         // n x npx
     double* mag;           // n x npx
     double* deg;           // n x npx
-    double* sn;            // n x npx : sin(deg), written where usedMap == 0 after the gradient pass
-    double* cs;            // n x npx : cos(deg), same
-    uint32_t* state;       // n x npx : usedMap value
+    double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
+    uint32_t* pw;          // n x npx : packed pixel word (see above)
+    uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3 (never initialised, read only behind code 3)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
@@ -45,16 +53,13 @@ struct Buffers {
     uint32_t* stamps;      // n x NW x npx : per-wave curMap stamps of the region stage
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
-    float* wmeta;          // n x NW x mcap x 2 : per list entry (reference angle, slack) of its last neighbourhood test
+    float4* wmeta;         // n x NW x mcap : per list entry (unit sum vector, sin of the smallest slack) of its last neighbourhood test
     int mcap;
     int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
-    // group-mode region growing (8 seeds per wavefront): per (image, wave, group) private storage
-    uint32_t* glist;       // n x NW x NB x 8 x gcap : region lists (grow order) of the blocks in flight
-    uint32_t* gwl;         // n x NW*8 x 2 x gcap : sweep worklists
-    uint16_t* gstamp;      // n x NW*8 x npx : curMap stamps (16-bit generations)
+    uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
-    double* pend;          // n x NW x NB x 8 x 24 : finished block results waiting for their turn to commit
+    double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
     int32_t* counts;       // n
@@ -82,11 +87,10 @@ void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
 // the region stage with 4 resp. 8 wavefronts per image (k_region.hip is compiled twice)
-void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
-void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, uint32_t id_base16, hipStream_t s);
-int region_groups();   // seed groups per image (NW * 8) of the wider variant: what the workspace is sized for
-int region_waves();    // wavefronts per image of the wider variant
-int region_blocks();   // block buffers per wave (glist and pend are sized x this)
+void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
+void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
+int region_slots();    // result slots per wavefront (slist and pend are sized x this)
+int region_waves();    // wavefronts per image of the wider variant: what the workspace is sized for
 int region_ring();     // commit-ring records per image (rnum is sized x this x 2)
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_match(const double* map_cache, int cols, int rows, const lsd_line* map_lines, const lsd_line* scan_lines,

@@ -154,6 +154,19 @@ def test_seed_trace_matches_oracle(maps, lsdmod, ctx, oracle):
     assert not seeds["logNFA"][~ev].any() and not rs["logNFA"][~ev].any()
 
 
+def test_fast_sincos_error_bound(lsdmod, ctx):
+    """RegionGrower's classifier works on fp32 ESTIMATES (k_region.hip): the unit vector of a pixel's packed angle -- fp32 with
+    the two lowest mantissa bits dropped, hardware sin/cos -- must lie within kEpsU = 4e-6 of the exact one; every margin
+    of the classifier is built on that bound (a candidate closer to the tolerance than the margins goes to the exact test)."""
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.uniform(-np.pi, np.pi, 4_000_000), np.linspace(-np.pi, np.pi, 200_001),
+                        np.array([0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, 1e-30, -1e-30, np.nextafter(np.pi, 0)]),
+                        rng.uniform(-1e-3, 1e-3, 100_000)])
+    s, c = ctx.eval_math(3, a)
+    err = np.hypot(s - np.sin(a), c - np.cos(a))
+    assert err.max() <= 3.0e-6, err.max()                                      # kEpsU = 4e-6 in k_region.hip
+
+
 def test_reference_names(maps, lsdmod, ctx, oracle):
     """myLineSegmentDetector / runLSD / structLSD as the reference spells them (LSD/myLSD.h:123-132)."""
     img = maps["map1"]
