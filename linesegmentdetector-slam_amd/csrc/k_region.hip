@@ -52,7 +52,7 @@ namespace RVAR {
 #define LSD_REGION_WAVES_PER_SIMD 2
 #endif
 #ifndef LSD_REGION_NS
-#define LSD_REGION_NS 8
+#define LSD_REGION_NS 16
 #endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
@@ -123,7 +123,30 @@ __shared__ int g_ttag[NW][NT];
 __shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
 __shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
+__shared__ double g_acc[NW][32 * 4];                      // staging of the serial (bit-exact) sums: 32 list elements x up to 4 terms
 
+// The reference's sums over a region (moments, angle sums, Refiner's statistics) are plain left-to-right fp64 additions, and
+// their rounding decides accept/reject ties, so they are added in exactly that order: the lanes compute the terms of 32 list
+// elements at a time and stage them in LDS, then lane j (j < 4) adds term j of the elements one after the other.  (One
+// ds_read + one v_add per element and sum, all sums at once, instead of broadcasting every term to every lane.)
+__device__ __forceinline__ void stage4(int wave, int lane, int half, double t0, double t1, double t2, double t3) {
+    if ((lane >> 5) == half) {
+        double* q = &g_acc[wave][(lane & 31) * 4];
+        q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3;
+    }
+}
+__device__ __forceinline__ double acc32(int wave, int lane, int cnt, double S) {   // cnt (wave-uniform) <= 32 staged elements
+    const double* q = &g_acc[wave][lane & 3];
+    int e = 0;
+    for (; e + 8 <= cnt; e += 8) {
+        S += q[(e + 0) * 4]; S += q[(e + 1) * 4]; S += q[(e + 2) * 4]; S += q[(e + 3) * 4];
+        S += q[(e + 4) * 4]; S += q[(e + 5) * 4]; S += q[(e + 6) * 4]; S += q[(e + 7) * 4];
+    }
+    for (; e < cnt; e++) S += q[e * 4];
+    return S;
+}
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
 __device__ __forceinline__ double rl(double v, int l) {  // broadcast lane l (l wave-uniform)
@@ -164,16 +187,16 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
     const int tx = px >> 3, ty = py >> 3;
     const int tile = need ? ty * c.tilesX + tx : -1;
     const int slot = tile_slot(tx, ty);
-    unsigned long long todo = __ballot(need && g_ttag[c.wave][slot] != tile);
+    unsigned long long todo = ballot64(need && g_ttag[c.wave][slot] != tile);
     if (!todo) return true;
     // conflict check over all needed tiles (resident ones included)
     {
-        unsigned long long chk = __ballot(need);
+        unsigned long long chk = ballot64(need);
         while (chk) {
             const int l = __builtin_ctzll(chk);
             const int T = __builtin_amdgcn_readlane(tile, l), S = __builtin_amdgcn_readlane(slot, l);
-            if (__ballot(need && slot == S && tile != T)) return false;
-            chk &= ~__ballot(tile == T);
+            if (ballot64(need && slot == S && tile != T)) return false;
+            chk &= ~ballot64(tile == T);
         }
     }
     [[maybe_unused]] const long long tt0 = NOW();
@@ -191,7 +214,7 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
                 const int l = __builtin_ctzll(todo);
                 T[j] = __builtin_amdgcn_readlane(tile, l);
                 S[j] = __builtin_amdgcn_readlane(slot, l);
-                todo &= ~__ballot(tile == T[j]);
+                todo &= ~ballot64(tile == T[j]);
                 nt++;
             }
         }
@@ -233,12 +256,14 @@ __device__ __forceinline__ void invalidate_tiles(const RCtx& c) {
 // ---------------------------------------------------------------------------------------------
 // (out of line, like every per-region stage below: each gets the register file to itself, and the seed loop keeps only
 //  what it needs across the calls; the context travels by value, the mutable state sits in LDS)
-__device__ __noinline__ void exact_sums(RCtx c, int n) {
-    if (g_ws[c.wave].ex_upto >= n) return;
+__device__ __noinline__ void exact_sums(RCtx c, int n_) {
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave), n = __builtin_amdgcn_readfirstlane(n_);
+    const int from = __builtin_amdgcn_readfirstlane(g_ws[wave].ex_upto);
+    if (from >= n) return;
     [[maybe_unused]] const long long t0 = NOW();
     const int lane = c.lane, w = c.w;
-    double sinS = g_ws[c.wave].ex_sin, cosS = g_ws[c.wave].ex_cos;
-    for (int base = g_ws[c.wave].ex_upto; base < n; base += 64) {
+    double S = lane == 0 ? g_ws[wave].ex_cos : g_ws[wave].ex_sin;      // lane 0: cosDeg, lane 1: sinDeg (:545-546)
+    for (int base = from; base < n; base += 64) {
         const int kx = base + lane;
         double vs = 0, vc = 0;
         if (kx < n) {
@@ -246,14 +271,15 @@ __device__ __noinline__ void exact_sums(RCtx c, int n) {
             const double2 v = c.sc[(size_t)(pk >> 16) * w + (pk & 0xffffu)];
             vs = v.x; vc = v.y;
         }
-        const int cnt = min(64, n - base);
-        if (cnt == 64) {
-            #pragma unroll
-            for (int j = 0; j < 64; j++) { cosS += rl(vc, j); sinS += rl(vs, j); }
-        } else
-        for (int j = 0; j < cnt; j++) { cosS += rl(vc, j); sinS += rl(vs, j); }
+        for (int half = 0; half < 2; half++) {
+            const int cnt = min(32, n - base - 32 * half);
+            if (cnt <= 0) break;
+            stage4(wave, lane, half, vc, vs, 0.0, 0.0);
+            S = acc32(wave, lane, cnt, S);
+        }
     }
-    if (lane == 0) { g_ws[c.wave].ex_sin = sinS; g_ws[c.wave].ex_cos = cosS; g_ws[c.wave].ex_upto = n; }
+    if (lane == 0) { g_ws[wave].ex_cos = S; g_ws[wave].ex_upto = n; }
+    if (lane == 1) g_ws[wave].ex_sin = S;
     DSTAT(ST_TSUMS, NOW() - t0);
 }
 
@@ -283,8 +309,9 @@ __device__ __noinline__ void exact_sums(RCtx c, int n) {
 // an upper bound of 1 / v for v >= 0.9 (v_rcp_f32 is good to 1 ulp; the margins it feeds are themselves upper bounds)
 __device__ __forceinline__ float inv_ub(float v) { return __builtin_amdgcn_rcpf(v) * 1.000001f; }
 
-constexpr float kEpsU = 4e-6f;     // >= |(cos, sin) estimate - exact|: 2-bit truncation of the fp32 angle (1e-6) + v_sin/v_cos_f32
-                                   //    (tests/test_parity_gpu.py::test_fast_sincos_error_bound measures the latter)
+constexpr float kEpsU = 6e-6f;     // >= |(cos, sin) estimate - exact| per accepted pixel: 2-bit truncation of the fp32 angle (1e-6) + v_sin/v_cos_f32
+                                   //    (together <= 3e-6: tests/test_parity_gpu.py::test_fast_sincos_error_bound) + the fp32 partial sums of
+                                   //    a batch (<= 64 terms: <= 2^-24 * 32 = 1.9e-6 per term); the running sums themselves are fp64
 constexpr float kInv2Pi = 0.15915494309189535f;
 
 __device__ __forceinline__ void fast_sincos(float a, float& s, float& co) {   // hardware sin/cos take revolutions
@@ -355,7 +382,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
         ws.cur_id = id; ws.members_cached = 1; ws.has_copy = 0; ws.ex_upto = 0; ws.ex_sin = 0.0; ws.ex_cos = 0.0;
     }
     ensure_tiles(c, lane == 0, sx, sy);
-    double Ce, Se;                                           // estimated sum vector
+    double Ce, Se;                                           // estimated sum vector (fp64 accumulation of the fp32 unit vectors)
     {
         const int slot = tile_slot(sx >> 3, sy >> 3), ti = ((sy & 7) << 3) | (sx & 7);
         const uint32_t sw = g_tw[wave][slot * 64 + ti];
@@ -415,7 +442,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
             flt_need = ((unsigned long long)(uint32_t)uni((int)(uint32_t)(flt_need >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)flt_need);
             // ---- the estimate of this batch (same in every lane) ----
             const float Cf = (float)Ce, Sf = (float)Se;
-            const float V2 = Cf * Cf + Sf * Sf;
+            const float V2 = __builtin_fmaf(Cf, Cf, Sf * Sf);
             const float rV = __builtin_amdgcn_rsqf(fmaxf(V2, 1e-12f)) * 1.000001f;   // >= 1 / |V|
             const float Vn = V2 * rV;                                                 // |V| (to 2e-6)
             const float nrat = (float)n * rV;                // >= n / |V|
@@ -432,13 +459,13 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                             const int ei = (int)g_wl[wave][wcur][wi + lane];
                             nd = true;
                             if (ei < mcap) {
-                                const nf4 mt = meta[ei];
+                                const nf4 mt = meta[(uint32_t)ei];
                                 const float vx = Cf * rV, vy = Sf * rV;                  // current unit sum vector (norm within 3e-6 of 1)
                                 const float dotv = mt.x * vx + mt.y * vy, crs = fabsf(mt.x * vy - mt.y * vx);
                                 nd = !(dotv > 0.0f && crs + 1e-5f + 2.0f * kEpsU * nrat < mt.z);
                             }
                         }
-                        flt_need = __ballot(nd);
+                        flt_need = ballot64(nd);
                         flt_valid = true;
                     }
                     const int off = wi - flt_base;
@@ -475,7 +502,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
             const int slot = tile_slot(tx, ty);
             const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
             uint32_t word_r = g_tw[wave][cell];
-            if (__ballot(inb && g_ttag[wave][slot] != ty * tilesX + tx)) {
+            if (ballot64(inb && g_ttag[wave][slot] != ty * tilesX + tx)) {
                 if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
                     cnt = 1;
                     valid = e < cnt;
@@ -485,7 +512,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 word_r = g_tw[wave][cell];
             }
             const bool cand = inb && (word_r & 3u) == 0u;    // :537: not in curMap, not banned (2 is growable, Q5)
-            const unsigned long long candm = __ballot(cand);
+            const unsigned long long candm = ballot64(cand);
             DSTAT(ST_BATCHES, 1);
             if (candm) {
                 const int q = ny * w + nx;
@@ -506,22 +533,22 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 bool bulk = false;
                 float dot = 0.0f;
                 if (tol_small) {
-                    const float m = (float)__builtin_popcountll(__ballot(winner));
-                    dot = cf * Cf + sf * Sf;                                          // ~ cos(distance) * |V|
+                    const float m = (float)__builtin_popcountll(ballot64(winner));
+                    dot = __builtin_fmaf(cf, Cf, sf * Sf);                            // ~ cos(distance) * |V|
                     const float eps_c = kEpsU * (1.0f + 2.1f * nrat) + 5e-6f;         // incl. the error of Vn
                     const float delta = m * turn * rV + 1e-7f;                        // |V| >= 1 here: accepted vectors only lengthen the sum
                     const float t_hi = delta <= tolf_lo ? (cos_tol + delta * sin_tol + eps_c) * Vn : 3e38f;
                     const float t_lo = delta <= 1.6f ? (cos_tol - delta * fminf(1.0f, sin_tol + delta) - eps_c) * Vn : -3e38f;
-                    const unsigned long long pcm = __ballot(cand && dot > t_hi);      // candidates that clearly pass
-                    const unsigned long long failm = __ballot(cand && dot < t_lo);    // ... clearly fail
+                    const unsigned long long pcm = ballot64(cand && dot > t_hi);      // candidates that clearly pass
+                    const unsigned long long failm = ballot64(cand && dot < t_lo);    // ... clearly fail
                     bulk = (candm & ~(pcm | failm)) == 0ull;
                     if (bulk && pcm) {
-                        const unsigned long long P = __ballot(winner && ((pcm >> lane) & 1ull));
+                        const unsigned long long P = ballot64(winner && ((pcm >> lane) & 1ull));
                         const int np = __builtin_popcountll(P);
                         if ((P >> lane) & 1ull) {
                             const int idx = n + mbcnt(P);
                             g_tw[wave][cell] = word_r | 2u;                           // :549
-                            stamp[q] = id;
+                            stamp[(uint32_t)q] = id;
                             if (n + 64 <= LCAP) g_lst[wave][idx] = pack_xy(nx, ny);   // :551-556
                             else lset(c, idx, pack_xy(nx, ny));
                         }
@@ -549,7 +576,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                         if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
                         const float cl = rlf(cf, l), sl = rlf(sf, l);
                         const float Cg = (float)Ce, Sg = (float)Se;
-                        const float Vg = sqrtf(Cg * Cg + Sg * Sg);
+                        const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
                         const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
                         int decided = -1;                    // 1 take, 0 reject, -1 exact test needed
                         if (tol_small) {
@@ -559,7 +586,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                             else if (d1 < (cos_tol - ec) * Vg) decided = 0;
                         } else if (Vg > 0.05f) {
                             // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
-                            const double R = n == 1 ? regDeg0 : atan2((double)Se, (double)Ce);
+                            const double R = n == 1 ? regDeg0 : atan2(Se, Ce);
                             const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
                             const double al = (double)rlf(af, l);
                             const double rw = fabs(R - al);
@@ -577,14 +604,14 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                         if (decided == 1) {
                             if (lane == l) {
                                 g_tw[wave][cell] = word_r | 2u;                       // :549
-                                stamp[q] = id;
+                                stamp[(uint32_t)q] = id;
                                 lset(c, n, pack_xy(nx, ny));                          // :551-556
                             }
                             Ce += (double)cl; Se += (double)sl;
                             n++;
                             g_ws[wave].dirty = 1;
                             flt_valid = false;
-                            gone |= __ballot(cand && q == ql);
+                            gone |= ballot64(cand && q == ql);
                         }
                     }
                 }
@@ -606,9 +633,9 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                         }
                         sg = min8(sg);
                         if (has && k == 0 && eidx < mcap)
-                            meta[eidx] = nf4{Cf * rV, Sf * rV, sg - 1.2e-4f - 8.0f * kEpsU * nrat, 0.0f};
+                            meta[(uint32_t)eidx] = nf4{Cf * rV, Sf * rV, sg - 1.2e-4f - 8.0f * kEpsU * nrat, 0.0f};
                     }
-                    const unsigned long long hm = __ballot(has && k == 0);
+                    const unsigned long long hm = ballot64(has && k == 0);
                     const int add = __builtin_popcountll(hm);
                     const bool room = nxt_cnt + add <= LCAP && n <= 65535;
                     g_wl[wave][wcur ^ 1][room && has && k == 0 ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
@@ -637,7 +664,8 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
 __device__ __noinline__ void rect_convert(RCtx c, int num, double regdeg, double aliPro, int pk, double tol) {
     const int lane = c.lane, w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
-    double cenX = 0, cenY = 0, ws = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave);
+    double S = 0;                                // serial accumulation in list order (bit-exact): lane 0 cenX, 1 cenY, 2 weight sum
     for (int base = 0; base < num; base += 64) {                                   // :608-613
         const int kx = base + lane;
         const bool valid = kx < num;
@@ -645,22 +673,18 @@ __device__ __noinline__ void rect_convert(RCtx c, int num, double regdeg, double
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         const double wgt = valid ? c.mag[(size_t)y * w + x] : 0.0;
         const double ax = wgt * x, ay = wgt * y;
-        const int cnt = min(64, num - base);
-        if (cnt == 64) {                         // full chunk: constant lane indices (no scalar loop overhead)
-            #pragma unroll
-            for (int j = 0; j < 64; j++) { cenX += rl(ax, j); cenY += rl(ay, j); ws += rl(wgt, j); }
-        } else
-        for (int j = 0; j < cnt; j++) {          // serial accumulation in list order (bit-exact)
-            cenX += rl(ax, j);
-            cenY += rl(ay, j);
-            ws += rl(wgt, j);
+        for (int half = 0; half < 2; half++) {
+            const int cnt = min(32, num - base - 32 * half);
+            if (cnt <= 0) break;
+            stage4(wave, lane, half, ax, ay, wgt, 0.0);
+            S = acc32(wave, lane, cnt, S);
         }
     }
-    cenX = cenX / ws;
-    cenY = cenY / ws;
+    double ws = rl(S, 2);
+    const double cenX = rl(S, 0) / ws;
+    const double cenY = rl(S, 1) / ws;
 
-    double Ixx = 0, Iyy = 0, Ixy = 0;
-    ws = 0;
+    S = 0;                                       // lane 0 Ixx, 1 Iyy, 2 Ixy, 3 weight sum
     for (int base = 0; base < num; base += 64) {                                   // :637-643
         const int kx = base + lane;
         const bool valid = kx < num;
@@ -669,19 +693,15 @@ __device__ __noinline__ void rect_convert(RCtx c, int num, double regdeg, double
         const double wgt = valid ? c.mag[(size_t)y * w + x] : 0.0;
         const double ddy = y - cenY, ddx = x - cenX;
         const double a = wgt * (ddy * ddy), b = wgt * (ddx * ddx), cc = wgt * ddx * ddy;
-        const int cnt = min(64, num - base);
-        if (cnt == 64) {
-            #pragma unroll
-            for (int j = 0; j < 64; j++) { Ixx += rl(a, j); Iyy += rl(b, j); Ixy -= rl(cc, j); ws += rl(wgt, j); }
-        } else
-        for (int j = 0; j < cnt; j++) {
-            Ixx += rl(a, j);
-            Iyy += rl(b, j);
-            Ixy -= rl(cc, j);
-            ws += rl(wgt, j);
+        for (int half = 0; half < 2; half++) {
+            const int cnt = min(32, num - base - 32 * half);
+            if (cnt <= 0) break;
+            stage4(wave, lane, half, a, b, -cc, wgt);     // Ixy -= cc (:642): adding the negated term is the same operation
+            S = acc32(wave, lane, cnt, S);
         }
     }
-    Ixx /= ws; Iyy /= ws; Ixy /= ws;
+    ws = rl(S, 3);
+    const double Ixx = rl(S, 0) / ws, Iyy = rl(S, 1) / ws, Ixy = rl(S, 2) / ws;
     const double dI = Ixx - Iyy;
     const double lamb = (Ixx + Iyy - sqrt(dI * dI + 4 * Ixy * Ixy)) / 2.0;          // :647
     double inertiaDeg;
@@ -875,7 +895,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
                 const double dv = c.deg[(size_t)j * xLim + g_sx[c.wave][ci]];
                 hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
             }
-            ali += __builtin_popcountll(__ballot(hit));
+            ali += __builtin_popcountll(ballot64(hit));
         }
     }
     if (all == 0 || ali == 0) return -logNT;                                       // :1019-1022
@@ -958,7 +978,8 @@ __device__ __noinline__ double refine_tol(RCtx c, int sx, int sy, int num, doubl
     const int lane = c.lane, w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
     const double rwid = g_ws[c.wave].rec.wid;
-    double difSum = 0, squSum = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave);
+    double S = 0;                                 // serial accumulation in list order: lane 0 difSum, 1 squSum
     int ptNum = 0;
     for (int base = 0; base < num; base += 64) {                                   // :839-853
         const int kx = base + lane;
@@ -976,15 +997,18 @@ __device__ __noinline__ double refine_tol(RCtx c, int sx, int sy, int num, doubl
             }
         }
         const double sq = degDif * degDif;
-        unsigned long long m = __ballot(flag);
-        while (m) {                               // serial accumulation in list order
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            difSum += rl(degDif, j);
-            squSum += rl(sq, j);
-            ptNum++;
+        const unsigned long long m = ballot64(flag);
+        if (m == 0ull) continue;
+        ptNum += __builtin_popcountll(m);
+        // (points outside the width contribute +0.0, which leaves a sum that started at +0.0 unchanged to the bit)
+        for (int half = 0; half < 2; half++) {
+            const int cnt = min(32, num - base - 32 * half);
+            if (cnt <= 0) break;
+            stage4(wave, lane, half, flag ? degDif : 0.0, flag ? sq : 0.0, 0.0, 0.0);
+            S = acc32(wave, lane, cnt, S);
         }
     }
+    const double difSum = rl(S, 0), squSum = rl(S, 1);
     const double meanDif = difSum / (ptNum * 1.0);
     DSTAT(ST_TREFINE, NOW() - t0);
     return 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
@@ -1046,15 +1070,16 @@ __device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __AT
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Commit ring: one record per seed in flight (index = seed number & (RW-1)).
-//   R_EMPTY  not evaluated yet, or evaluated with a result that marks usedMap ("heavy": stashed in one of its owner's
-//            slots; the owner commits it itself when the cursor reaches it)
+//   R_EMPTY  not evaluated yet
+//   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (lref);
+//            whoever moves the cursor over it validates and commits it
 //   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
 //   R_LIGHT  evaluated, no marks to make (small region :228 or refine failed :237); whoever advances the
 //            cursor checks that no line accepted since the record's snapshot touches what it examined
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
 //   R_BUSY   being re-evaluated at the cursor
-enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4 };
-constexpr int RW = 256;
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5 };
+constexpr int RW = NW == 4 ? 128 : 256;   // records in flight (> NW * NS + run-ahead over skipped seeds)
 
 struct Ring {
     int state[RW];
@@ -1069,7 +1094,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
 
-    const size_t img = blockIdx.x;
+    const size_t img = b.order[blockIdx.x];               // heaviest images first (k_order)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = g.w, h = g.h;
     const size_t npx = (size_t)g.npx;
@@ -1108,7 +1133,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         for (int base = 0; base < nb; base += 64) {
             const int idx = base + lane;
             const bool ok = idx < nb && (c.pw[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
-            const unsigned long long m = __ballot(ok);
+            const unsigned long long m = ballot64(ok);
             if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
             cnt += __builtin_popcountll(m);
         }
@@ -1161,9 +1186,39 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 }
             }
         }
-        return __ballot(hit) != 0ull;
+        return ballot64(hit) != 0ull;
     };
-    // Moves the commit cursor over finished records (one wave at a time).
+    // Commits a result that marks usedMap (accepted line: code 3 + epoch; rejected region: code 2), at the cursor, under
+    // the cursor lock: pv = lane j < 12: field j of the rectangle (structRec order); m_src: the pixels to mark (null: this
+    // wave's own last grow).
+    auto commit_marks = [&](int k, int num0, int fnum, int outcome, double logNFA, double pv, const uint32_t* m_src, int m_cnt) {
+        write_trace(k, num0, fnum, outcome, logNFA);
+        if (outcome == 2) {                                                          // :242-250
+            (void)mark_region(c, 0u, m_src, m_cnt);
+        } else if (outcome == 3) {
+            const int li = s_lines;
+            if (li < b.max_lines) {
+                if (lane < 12) recs[(size_t)li * 12 + lane] = pv;                    // structRec as accepted
+                if (lane < 4) recs_scaled[(size_t)li * 4 + lane] = g.sca != 1 ? (pv - 1.0) / g.sca + 1 : pv;   // x1 y1 x2 y2, :252-258
+            }
+            const Box mb = mark_region(c, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
+            wg_fence();                                   // the marks must be visible before the epoch moves
+            if (lane == 0) {
+                const int ep = s_epoch;
+                short* r = s_ring[ep & (RING - 1)];
+                r[0] = (short)mb.x0; r[1] = (short)mb.y0; r[2] = (short)mb.x1; r[3] = (short)mb.y1;
+                s_lines = li + 1;
+                lds_st(&s_epoch, ep + 1);
+            }
+            invalidate_tiles(c);                          // this wave's cached ban flags are stale now
+            g_ws[wave].cache_epoch = -1;
+        }
+        wg_fence();                                       // marks + ring visible before the cursor moves
+    };
+    // Moves the commit cursor over finished records (one wave at a time, whichever comes by): skipped seeds, results
+    // without marks (after checking that they are still valid), and STASHED results of ANY wave -- everything a commit
+    // needs sits in the owner's result slot in HBM, so the cursor never waits for an owner that is busy with a long
+    // speculative evaluation further ahead.
     auto advance = [&]() {
         int got = 0;
         if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0 ? 1 : 0;
@@ -1172,33 +1227,66 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         while (true) {
             const int f = lds_ld(&s_commit);
             if (f >= nseeds) break;
-            const int st = lds_ld(&rg.state[f & (RW - 1)]);
+            const int r = f & (RW - 1);
+            const int st = lds_ld(&rg.state[r]);
             if (st == R_SKIP) {
-                if (lane == 0) { rg.state[f & (RW - 1)] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             if (st == R_LIGHT) {
-                const int snap = rg.snap[f & (RW - 1)], now = lds_ld(&s_epoch);
-                const short* bx = rg.box[f & (RW - 1)];
+                const int snap = rg.snap[r], now = lds_ld(&s_epoch);
+                const short* bx = rg.box[r];
                 if (now != snap && hit_since(snap, now, bx[0], bx[1], bx[2], bx[3])) {
-                    const uint32_t lr = rg.lref[f & (RW - 1)], lc = rg.lcnt[f & (RW - 1)];
+                    const uint32_t lr = rg.lref[r], lc = rg.lcnt[r];
                     bool conflict = true;
                     if (lr != ~0u) {                       // the lists are still in their slot: look at the pixels themselves
                         wg_fence();
                         conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
                     }
                     if (conflict) {
-                        if (lane == 0) lds_st(&rg.state[f & (RW - 1)], R_REDO);
+                        if (lane == 0) lds_st(&rg.state[r], R_REDO);
                         break;
                     }
                 }
                 bool used_now = false;
                 if (trace) used_now = (c.pw[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
                 if (trace && !used_now) {
-                    const int no = rnum[(f & (RW - 1)) * 2 + 1];
-                    write_trace(f, rnum[(f & (RW - 1)) * 2], no >> 2, no & 3, 0.0);
+                    const int no = rnum[r * 2 + 1];
+                    write_trace(f, rnum[r * 2], no >> 2, no & 3, 0.0);
                 } else if (!trace) write_trace(f, 0, 0, 0, 0.0);
-                if (lane == 0) { rg.state[f & (RW - 1)] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                continue;
+            }
+            if (st == R_STASH) {
+                // ---- a stashed result at the cursor: is it still what the sequential run would get? ----
+                const uint32_t lr = rg.lref[r];
+                wg_fence();
+                const double pv = b.pend[(img * (size_t)(NW * NS) + lr) * 24 + (lane < 24 ? lane : 0)];
+                const double logNFA = rl(pv, 12);
+                const int outcome = (int)rl(pv, 14), num0 = (int)rl(pv, 15), num = (int)rl(pv, 16), m_cnt = (int)rl(pv, 17);
+                const int x0 = (int)rl(pv, 18), y0 = (int)rl(pv, 19), x1 = (int)rl(pv, 20), y1 = (int)rl(pv, 21);
+                const int snap = (int)rl(pv, 23);
+                const long long pk3 = (long long)rl(pv, 22);
+                const int st_n1 = (int)(pk3 % 32768ll) - 1, st_n2 = (int)((pk3 / 32768ll) % 32768ll);
+                const uint32_t* st_list = b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap;
+                const uint32_t* m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
+                if ((c.pw[ord[seedidx[f]]] & 3u) != 0u) {  // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
+                    STAT(ST_DISCARD, 1);
+                    if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                    continue;
+                }
+                const int now = lds_ld(&s_epoch);
+                if (now != snap && hit_since(snap, now, x0, y0, x1, y1)) {
+                    bool conflict = true;
+                    if (st_n1 >= 0) conflict = examined_hit(st_list, st_n1 + st_n2, snap);   // the pixels themselves
+                    if (conflict) {
+                        STAT(ST_REDO, 1);
+                        if (lane == 0) lds_st(&rg.state[r], R_REDO);     // evaluate again; everything earlier is committed now
+                        break;
+                    }
+                }
+                commit_marks(f, num0, num, outcome, logNFA, pv, m_src, m_cnt);
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             break;
@@ -1206,14 +1294,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (lane == 0) lds_st(&s_lock, 0);
     };
 
-    // Result slots of this wave: slot s holds the lists of the speculative result of seed slot_k (lane s of slot_k_l);
-    // it is free again once the cursor has passed that seed.  Results that mark usedMap ("heavy") are stashed -- record
-    // in pend[], pixels to mark in the slot -- and committed by this wave when the cursor reaches them.
+    // Result slots of this wave: slot s holds the lists (and, for a result that marks usedMap, the record in pend[]) of
+    // the speculative result of seed slot_k (lane s of slot_k_l); it is free again once the cursor has passed that seed.
     uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
     int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
-    unsigned stash_mask = 0;                               // slots holding a stashed result
-    int forced_k = -1;                                     // seed to (re)evaluate non-speculatively at the cursor
     const unsigned long long ltm = (1ull << lane) - 1ull;
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
@@ -1221,20 +1306,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     while (true) {
         // ---- choose the next job ----
         int k, slot = 0;
-        bool spec, from_stash = false;
-        int epoch_snap;
+        bool spec;
         LT(ST_TSELECT);
         const int f = lds_ld(&s_commit);
-        int kp = -1, kp_slot = 0;                          // earliest stashed result of this wave
-        if (stash_mask) {
-            const int v = (lane < NS && ((stash_mask >> lane) & 1u)) ? slot_k_l : 0x7fffffff;
-            int mv = v;
-            for (int off = 1; off < NS; off <<= 1) mv = min(mv, __shfl_xor(mv, off));
-            kp = __builtin_amdgcn_readfirstlane(mv);
-            kp_slot = __builtin_ctzll(__ballot(lane < NS && v == kp));
-        }
-        if (forced_k >= 0) { k = forced_k; spec = false; forced_k = -1; }
-        else {
+        {
             // a record waiting to be redone at the cursor has priority
             int won = 0;
             if (f < nseeds && lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) {
@@ -1242,13 +1317,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 won = __builtin_amdgcn_readfirstlane(won);
             }
             if (won) { k = f; spec = false; }
-            else if (kp == f) {
-                // ---- the cursor is at a stashed result of this wave: commit it ----
-                k = kp; slot = kp_slot;
-                from_stash = true; spec = true;
-            } else {
+            else {
                 // a free slot (the cursor has passed its seed) and a seed left to hand out?
-                const unsigned long long freem = __ballot(lane < NS && slot_k_l < f);
+                const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
                 bool took = false;
                 if (freem && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - 2 * NW) {
                     int k0 = 0;
@@ -1257,25 +1328,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (k0 < nseeds) { k = k0; slot = __builtin_ctzll(freem); spec = true; took = true; }
                 }
                 if (!took) {
-                    if (kp >= 0) {
-                        // ---- nothing else to do: wait for the turn of the earliest stashed result ----
-                        [[maybe_unused]] const long long tw0 = NOW();
-                        while (true) {
-                            advance();
-                            const int f2 = lds_ld(&s_commit);
-                            if (f2 == kp) break;
-                            if (f2 < nseeds && lds_ld(&rg.state[f2 & (RW - 1)]) == R_REDO) break;   // somebody has to redo f2 (top of the loop)
-                            if (__ballot(lane < NS && slot_k_l < f2) && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f2 < RW - 2 * NW) break;   // a slot came free
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                        tl = NOW();
-                        DSTAT(ST_WAIT, tl - tw0);
-                        continue;
-                    }
                     advance();
                     if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
-                    __builtin_amdgcn_s_sleep(2);           // nothing left to hand out, or every slot waits for the cursor
-                    LT(ST_TIDLE);
+                    if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(8);   // nothing moved: every slot waits for the cursor, or nothing is left to hand out
+                    LT(ST_WAIT);
                     continue;
                 }
             }
@@ -1288,36 +1344,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         double logNFA = 0;
         double pv = 0;                                     // lane j < 12: field j of the result's rectangle (structRec order)
         int rec_pk = 0;
-        bool skip = false;
-        const uint32_t* m_src = nullptr;                   // stashed pixel list to mark at commit (else the wave's own list)
-        int m_cnt = 0;
-        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;              // box of everything the evaluation examined
-        int st_n1 = -1, st_n2 = 0;                         // stashed result: sizes of the lists kept in its slot (-1: none)
-        const uint32_t* st_list = nullptr;
-        if (from_stash) {
-            stash_mask &= ~(1u << slot);
-            wg_fence();
-            pv = wave_pend[slot * 24 + (lane < 24 ? lane : 0)];
-            logNFA = rl(pv, 12);
-            rec_pk = (int)rl(pv, 13); outcome = (int)rl(pv, 14); num0 = (int)rl(pv, 15); num = (int)rl(pv, 16); m_cnt = (int)rl(pv, 17);
-            x0 = (int)rl(pv, 18); y0 = (int)rl(pv, 19); x1 = (int)rl(pv, 20); y1 = (int)rl(pv, 21);
-            epoch_snap = (int)rl(pv, 23);
-            {
-                const long long pk3 = (long long)rl(pv, 22);
-                st_n1 = (int)(pk3 % 32768ll) - 1; st_n2 = (int)((pk3 / 32768ll) % 32768ll);
-                st_list = wave_slist + (size_t)slot * b.gcap;
-                m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
-            }
-        } else {
         // ---- evaluate ----
         if (lane == slot && spec) slot_k_l = k;            // the slot is taken until the cursor has passed seed k
-        epoch_snap = lds_ld(&s_epoch);                     // before anything of usedMap is read for this seed
+        const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
         wg_fence();
-        if (!spec || epoch_snap != g_ws[c.wave].cache_epoch) {    // tiles fetched before the last accept may miss its bans
+        if (!spec || epoch_snap != g_ws[wave].cache_epoch) {   // tiles fetched before the last accept may miss its bans
             invalidate_tiles(c);
-            if (lane == 0) g_ws[c.wave].cache_epoch = epoch_snap;
+            g_ws[wave].cache_epoch = epoch_snap;
         }
-        skip = (c.pw[pp] & 3u) != 0u;                      // monotone: once used, always used (:222)
+        const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
         uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
@@ -1341,10 +1376,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     num0 = num;
                     if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
                 } else if (num < 2) { outcome = 1; done = true; break; }              // :861
-                if (num > 1) { exact_sums(c, num); regdeg = atan2_g(g_ws[c.wave].ex_sin, g_ws[c.wave].ex_cos); }   // reg.deg (:547, :581)
+                if (num > 1) { exact_sums(c, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
                 else regdeg = seedDeg;
                 rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre);                 // :232 / :866 (p, prec still the defaults)
-                const double den = rec_density(num, g_ws[c.wave].rec);
+                const double den = rec_density(num, g_ws[wave].rec);
                 if (pass == 0) {
                     if (den >= g.denThre) break;                                      // :829 dense enough
                     if (spec) {                                                       // the regrow replaces this list
@@ -1362,73 +1397,75 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (!done) {
                 logNFA = improve(c);                                                  // :240
                 outcome = logNFA <= 0 ? 2 : 3;                                        // :242
-                pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[c.wave].rec)[lane] : 0.0;
-                rec_pk = g_ws[c.wave].rec.pk;
+                pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;
+                rec_pk = g_ws[wave].rec.pk;
             }
         }
-        const int gnum = g_ws[c.wave].gnum;                       // size of the last grow (grow order)
-        const bool has_copy = g_ws[c.wave].has_copy != 0;
+        const int gnum = g_ws[wave].gnum;                  // size of the last grow (grow order)
+        const bool has_copy = g_ws[wave].has_copy != 0;
 
         // ---- hand the result over ----
         LT(ST_TEVAL);
-        if (spec) {
-            if (skip) {
-                if (lane == slot) slot_k_l = -1;           // nothing kept in the slot
-                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
-                advance();
-                continue;
+        if (!spec) {
+            // ---- evaluated at the cursor (k == s_commit, record R_BUSY: nobody else can commit): commit right away ----
+            if (!skip && outcome >= 2) commit_marks(k, num0, num, outcome, logNFA, pv, nullptr, 0);
+            else if (!skip) write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
+            wg_fence();
+            if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
+            LT(ST_TCOMMIT);
+            continue;
+        }
+        if (skip) {
+            if (lane == slot) slot_k_l = -1;               // nothing kept in the slot
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
+            advance();
+            continue;
+        }
+        // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
+        int x0, y0, x1, y1;
+        {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
+            Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
+            fb = list_bbox(c, gnum, fb, has_copy);
+            x0 = fb.x0 - 1; y0 = fb.y0 - 1; x1 = fb.x1 + 1; y1 = fb.y1 + 1;
+        }
+        bool precise = n1 >= 0;
+        int n2 = 0;
+        if (regrown) {                                     // keep Refiner's regrow (in grow order, before any reduction) behind the first list
+            if (precise && n1 + gnum <= b.gcap) {
+                for (int k2 = lane; k2 < gnum; k2 += 64) gl0[n1 + k2] = has_copy ? c.gcopy[k2] : lget(c, k2);
+                n2 = gnum;
+            } else precise = false;
+        }
+        if (n1 > 32767 || n2 > 32767) precise = false;     // (the sizes travel in 15-bit fields)
+        if (outcome <= 1) {                                // nothing to mark: publish and move on
+            if (lane == 0) {
+                const int r = k & (RW - 1);
+                rg.snap[r] = epoch_snap;
+                rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
+                rg.lref[r] = precise ? (uint32_t)(wave * NS + slot) : ~0u;
+                rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
+                if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
             }
-            // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
-            {                                              // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
-                Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-                fb = list_bbox(c, gnum, fb, has_copy);
-                x0 = fb.x0 - 1; y0 = fb.y0 - 1; x1 = fb.x1 + 1; y1 = fb.y1 + 1;
-            }
-            bool precise = n1 >= 0;
-            int n2 = 0;
-            if (regrown) {                                 // keep Refiner's regrow (in grow order, before any reduction) behind the first list
-                if (precise && n1 + gnum <= b.gcap) {
-                    for (int k2 = lane; k2 < gnum; k2 += 64) gl0[n1 + k2] = has_copy ? c.gcopy[k2] : lget(c, k2);
-                    n2 = gnum;
-                } else precise = false;
-            }
-            if (n1 > 32767 || n2 > 32767) precise = false; // (the sizes travel in 15-bit fields)
-            if (outcome <= 1) {                            // nothing to mark: publish and move on
-                if (lane == 0) {
-                    const int r = k & (RW - 1);
-                    rg.snap[r] = epoch_snap;
-                    rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
-                    rg.lref[r] = precise ? (uint32_t)(wave * NS + slot) : ~0u;
-                    rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
-                    if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
-                }
-                wg_fence();                                // the lists are in the slot before the record says so
-                if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
-                advance();
-                continue;
-            }
-            // marks to make: stash the result (record in pend[], the pixels to mark in the list slot) and carry on
-            int m_off = 0, mcnt = num;                     // not regrown: the first list is exactly the region
-            if (!regrown) {
-                if (!precise) {                            // (larger than a list slot) evaluate again at the cursor
-                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
-                    STAT(ST_REDO, 1);
-                    advance();
-                    continue;
-                }
-            } else if (precise && !has_copy) { m_off = n1; mcnt = n2; }        // the regrow as it is
+            wg_fence();                                    // the lists are in the slot before the record says so
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
+            advance();
+            continue;
+        }
+        // marks to make: stash the result (record in pend[], the pixels to mark in the list slot); whoever moves the
+        // cursor over it commits it
+        int m_off = 0, mcnt = num;                         // not regrown: the first list is exactly the region
+        bool redo = false;
+        if (!regrown) {
+            if (!precise) redo = true;                     // (larger than a list slot) evaluate again at the cursor
+        } else if (precise && !has_copy) { m_off = n1; mcnt = n2; }            // the regrow as it is
+        else {
+            m_off = precise ? n1 + n2 : 0;
+            if (m_off + gnum > b.gcap) { precise = false; m_off = 0; }
+            if (gnum > b.gcap) redo = true;
             else {
-                m_off = precise ? n1 + n2 : 0;
-                if (m_off + gnum > b.gcap) { precise = false; m_off = 0; }
-                if (gnum > b.gcap) {
-                    if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
-                    STAT(ST_REDO, 1);
-                    advance();
-                    continue;
-                }
                 wg_fence();                                // the stamps written by grow() must have landed
-                if (lane == 0) g_ws[c.wave].dirty = 0;
-                const uint32_t cur_id = g_ws[c.wave].cur_id;
+                g_ws[wave].dirty = 0;
+                const uint32_t cur_id = g_ws[wave].cur_id;
                 mcnt = 0;
                 for (int base = 0; base < gnum; base += 64) {
                     const int k2 = base + lane;
@@ -1438,75 +1475,31 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         pkx = has_copy ? c.gcopy[k2] : lget(c, k2);
                         keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == cur_id;   // curMap == 1 only
                     }
-                    const unsigned long long km = __ballot(keep);
+                    const unsigned long long km = ballot64(keep);
                     if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
                     mcnt += __builtin_popcountll(km);
                 }
             }
-            if (lane < 12) wave_pend[slot * 24 + lane] = pv;
-            if (lane == 0) {
-                double* P = wave_pend + slot * 24;
-                P[12] = logNFA;
-                P[13] = (double)rec_pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
-                P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
-                P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
-                P[23] = (double)epoch_snap;
-            }
-            wg_fence();
-            stash_mask |= 1u << slot;
+        }
+        if (redo) {
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
+            STAT(ST_REDO, 1);
+            advance();
             continue;
         }
-        }   // !from_stash
-
-        LT(ST_TSELECT);
-        if (spec) {
-            // ---- a stashed result at the cursor (k == s_commit): is it still what the sequential run would get? ----
-            wg_fence();
-            bool bad = (c.pw[pp] & 3u) != 0u;              // an earlier seed marked the pixel meanwhile
-            if (bad) {
-                STAT(ST_DISCARD, 1);
-                if (lane == 0) { lds_st(&s_commit, k + 1); }
-                continue;
-            }
-            const int now = lds_ld(&s_epoch);
-            if (now != epoch_snap && hit_since(epoch_snap, now, x0, y0, x1, y1)) {
-                bool conflict = true;
-                if (st_n1 >= 0) conflict = examined_hit(st_list, st_n1 + st_n2, epoch_snap);   // the pixels themselves
-                if (conflict) {
-                    STAT(ST_REDO, 1);
-                    forced_k = k;                          // evaluate again; everything earlier is committed now
-                    continue;
-                }
-            }
+        if (lane < 12) wave_pend[slot * 24 + lane] = pv;
+        if (lane == 0) {
+            double* P = wave_pend + slot * 24;
+            P[12] = logNFA;
+            P[13] = (double)rec_pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)mcnt;
+            P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
+            P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
+            P[23] = (double)epoch_snap;
+            rg.lref[k & (RW - 1)] = (uint32_t)(wave * NS + slot);
         }
-
-        // ---- commit at the cursor (k == s_commit, nobody else can commit) ----
-        if (!skip) {
-            write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
-            if (outcome == 2) {                                                      // :242-250
-                (void)mark_region(c, 0u, m_src, m_cnt);
-            } else if (outcome == 3) {
-                const int li = s_lines;
-                if (li < b.max_lines) {
-                    if (lane < 12) recs[(size_t)li * 12 + lane] = pv;                // structRec as accepted
-                    if (lane < 4) recs_scaled[(size_t)li * 4 + lane] = g.sca != 1 ? (pv - 1.0) / g.sca + 1 : pv;   // x1 y1 x2 y2, :252-258
-                }
-                const Box mb = mark_region(c, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
-                wg_fence();                               // the marks must be visible before the epoch moves
-                if (lane == 0) {
-                    const int ep = s_epoch;
-                    short* r = s_ring[ep & (RING - 1)];
-                    r[0] = (short)mb.x0; r[1] = (short)mb.y0; r[2] = (short)mb.x1; r[3] = (short)mb.y1;
-                    s_lines = li + 1;
-                    lds_st(&s_epoch, ep + 1);
-                }
-                invalidate_tiles(c);                      // this wave's cached ban flags are stale now
-                if (lane == 0) g_ws[c.wave].cache_epoch = -1;
-            }
-        }
-        wg_fence();                                       // marks + ring visible before the cursor moves
-        if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
-        LT(ST_TCOMMIT);
+        wg_fence();                                        // record and lists are in the slot before the ring says so
+        if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_STASH);
+        advance();
     }
 
     __syncthreads();

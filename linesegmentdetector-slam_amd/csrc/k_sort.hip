@@ -104,6 +104,33 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     }
 }
 
+// Heaviest images first: the region stage costs roughly what the number of sortable pixels says, and its workgroups are
+// dispatched in index order, so the batch is handed to it in descending order of nb (longest-processing-time-first
+// keeps the tail of the launch short).  One workgroup; counting sort of the images over 256 quantised keys.
+__global__ __launch_bounds__(256) void k_order(const int32_t* __restrict__ nb, uint32_t* __restrict__ order, int n, int npx) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t start[256];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    auto key = [&](int i) { return 255 - (int)min(255ll, (long long)nb[i] * 2048 / (npx + 1)); };   // (nb is ~7 % of npx on occupancy maps)
+    for (int i = tid; i < n; i += 256) atomicAdd(&cnt[key(i)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int k2 = 0; k2 < 256; k2++) { start[k2] = run; run += cnt[k2]; }
+    }
+    __syncthreads();
+    // stable within a key (ascending image index), so the order is deterministic: one thread per key walks the images
+    uint32_t pos = start[tid];
+    for (int i = 0; i < n; i++)
+        if (key(i) == tid) order[pos++] = (uint32_t)i;
+}
+
+void launch_order(const Buffers& b, int n, int npx, hipStream_t s) {
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(256), 0, s, b.nb, b.order, n, npx);
+}
+
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const size_t lds = ((size_t)SWAVES * g.pseBin + SWAVES) * sizeof(uint32_t);
     // 16 x 1024 bins x 4 B is just over the 64 KiB default; gfx950 has 160 KiB of LDS per CU

@@ -31,6 +31,7 @@ struct lsd_ctx {
     // workspace
     double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
     double2* sc = nullptr;
+    uint32_t* order = nullptr;
     uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
     uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number (a wave that uses up its 2^20 clears its stamps)
     uint32_t* slist = nullptr;
@@ -38,7 +39,7 @@ struct lsd_ctx {
     float4* wmeta = nullptr;
     int* rnum = nullptr;
     int mcap = 16384;
-    int gcap = 16384;
+    int gcap = 8192;
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
@@ -191,7 +192,9 @@ static hipError_t re_alloc(T** p, size_t count) {
 
 // wavefronts per image of the region-stage build a batch of n images runs on (see launch below)
 static int waves_for(const lsd_ctx* c, int n) {
-    if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= c->num_cus)) return 8;
+    // 8 wavefronts per image (one image per CU) finish an image ~1.5x sooner; 4 (two images per CU) have the higher throughput.
+    // While the batch is only a few images per CU its time is that of its heaviest images: 8.  Long batches: 4.
+    if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= 4 * c->num_cus)) return 8;
     return 4;
 }
 
@@ -213,6 +216,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, in
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->pend, gs * 24));
+        HIPCHK(c, re_alloc(&c->order, nn));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
@@ -242,7 +246,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->slist, (void**)&c->pend,
+                         (void**)&c->seedidx, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
@@ -308,7 +312,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->slist, c->pend, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -369,7 +373,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
-    b.slist = c->slist; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
+    b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
@@ -386,7 +390,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_GRAD) launch_gradient(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) launch_sort(g, b, n, s);
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) { launch_sort(g, b, n, s); launch_order(b, n, g.npx, s); }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range

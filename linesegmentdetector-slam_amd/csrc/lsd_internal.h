@@ -56,6 +56,7 @@ struct Buffers {
     float4* wmeta;         // n x NW x mcap : per list entry (unit sum vector, sin of the smallest slack) of its last neighbourhood test
     int mcap;
     int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
+    uint32_t* order;       // n : image indices, heaviest (largest nb) first: the region stage's workgroup -> image map
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
@@ -86,6 +87,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_order(const Buffers& b, int n, int npx, hipStream_t s);
 // the region stage with 4 resp. 8 wavefronts per image (k_region.hip is compiled twice)
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
 void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
