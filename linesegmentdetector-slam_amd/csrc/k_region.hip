@@ -149,6 +149,34 @@ __device__ __forceinline__ double acc32(int wave, int lane, int cnt, double S) {
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
+// Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
+// the scalar unit (scalar compares and branches, SGPR-base addressing of global memory with 32-bit lane offsets).
+#define AS1 __attribute__((address_space(1)))
+typedef float nf4 __attribute__((ext_vector_type(4)));       // (HIP's float4 class cannot be reached through an address-space pointer)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class T>
+__device__ __forceinline__ AS1 T* uglobal(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (AS1 T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int mbcnt(unsigned long long m) {   // number of set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// minimum over the 8 lanes of a group (lane >> 3), every lane gets it: three DPP steps, no LDS traffic
+__device__ __forceinline__ float min8(float v) {
+    int t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+    t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+    t = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xf, 0xf, false)));  // row_half_mirror
+    return v;
+}
+
 __device__ __forceinline__ double rl(double v, int l) {  // broadcast lane l (l wave-uniform)
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);
@@ -182,12 +210,14 @@ __device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx + 5 * ty) 
 
 // Makes the tiles of every lane with need==true resident.  Returns false when two needed tiles map
 // to the same slot (the caller retries with a smaller batch; a single 3x3 neighbourhood never conflicts).
+// A tile's tag is (tile row << 16 | tile column).
+__device__ __forceinline__ int tile_key(int tx, int ty) { return (ty << 16) | tx; }
 __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, int py) {
-    const int lane = c.lane, w = c.w, h = c.h;
+    const int lane = c.lane, w = c.w, h = c.h, wave = c.wave;
     const int tx = px >> 3, ty = py >> 3;
-    const int tile = need ? ty * c.tilesX + tx : -1;
+    const int tile = need ? tile_key(tx, ty) : -1;
     const int slot = tile_slot(tx, ty);
-    unsigned long long todo = ballot64(need && g_ttag[c.wave][slot] != tile);
+    unsigned long long todo = ballot64(need & (g_ttag[wave][slot] != tile));
     if (!todo) return true;
     // conflict check over all needed tiles (resident ones included)
     {
@@ -195,14 +225,17 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
         while (chk) {
             const int l = __builtin_ctzll(chk);
             const int T = __builtin_amdgcn_readlane(tile, l), S = __builtin_amdgcn_readlane(slot, l);
-            if (ballot64(need && slot == S && tile != T)) return false;
+            if (ballot64(need & (slot == S) & (tile != T))) return false;
             chk &= ~ballot64(tile == T);
         }
     }
     [[maybe_unused]] const long long tt0 = NOW();
-    if (__builtin_amdgcn_readfirstlane(g_ws[c.wave].dirty)) { wg_fence(); g_ws[c.wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
+    if (__builtin_amdgcn_readfirstlane(g_ws[wave].dirty)) { wg_fence(); g_ws[wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
     DSTAT(ST_TILEFETCH, 1);
-    const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[c.wave].cur_id);
+    const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[wave].cur_id);
+    AS1 const uint32_t* const pw = uglobal(c.pw);
+    AS1 const uint32_t* const stamp = uglobal(c.stamp);
+    const int lx = lane & 7, ly = lane >> 3;
     while (todo) {
         // up to 4 missing tiles per round, all loads in flight together
         int T[4], S[4];
@@ -223,20 +256,19 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
         for (int j = 0; j < 4; j++) {
             vw[j] = kPwStatic; vs[j] = 0u;                        // outside the image: banned
             if (j < nt) {
-                const int ttx = T[j] % c.tilesX, tty = T[j] / c.tilesX;
-                const int x = ttx * 8 + (lane & 7), y = tty * 8 + (lane >> 3);
-                if (x < w && y < h) {
-                    const size_t q = (size_t)y * w + x;
-                    vw[j] = c.pw[q];
-                    vs[j] = c.stamp[q];
+                const int x = (T[j] & 0xffff) * 8 + lx, y = (T[j] >> 16) * 8 + ly;
+                if ((x < w) & (y < h)) {
+                    const uint32_t q = (uint32_t)(y * w + x);
+                    vw[j] = pw[q];
+                    vs[j] = stamp[q];
                 }
             }
         }
         #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nt) {
-                g_tw[c.wave][S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
-                g_ttag[c.wave][S[j]] = T[j];               // (all lanes, same value)
+                g_tw[wave][S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
+                g_ttag[wave][S[j]] = T[j];                 // (all lanes, same value)
             }
         }
     }
@@ -320,42 +352,14 @@ __device__ __forceinline__ void fast_sincos(float a, float& s, float& co) {   //
     co = __builtin_amdgcn_cosf(r);
 }
 
-// Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
-// the scalar unit (scalar compares and branches, SGPR-base addressing of global memory with 32-bit lane offsets).
-#define AS1 __attribute__((address_space(1)))
-typedef float nf4 __attribute__((ext_vector_type(4)));       // (HIP's float4 class cannot be reached through an address-space pointer)
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-template <class T>
-__device__ __forceinline__ AS1 T* uglobal(T* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (AS1 T*)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ int mbcnt(unsigned long long m) {   // number of set bits of m below this lane
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-// minimum over the 8 lanes of a group (lane >> 3), every lane gets it: three DPP steps, no LDS traffic
-__device__ __forceinline__ float min8(float v) {
-    int t = __float_as_int(v);
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
-    t = __float_as_int(v);
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
-    t = __float_as_int(v);
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xf, 0xf, false)));  // row_half_mirror
-    return v;
-}
-
 __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, double tol_) {
     const int lane = c.lane;
     const double regDeg0 = uni(regDeg0_), tol = uni(tol_);
-    const int w = uni(c.w), h = uni(c.h), wave = uni(c.wave), tilesX = uni(c.tilesX), mcap = uni(c.mcap);
+    const int w = uni(c.w), h = uni(c.h), wave = uni(c.wave), mcap = uni(c.mcap);
     const int sx = uni(sx_), sy = uni(sy_);
     AS1 uint32_t* const stamp = uglobal(c.stamp);
     AS1 nf4* const meta = (AS1 nf4*)uglobal(c.meta);
-    c.w = w; c.h = h; c.wave = wave; c.tilesX = tilesX;      // (what the helpers below read)
+    c.w = w; c.h = h; c.wave = wave;                         // (what the helpers below read)
     [[maybe_unused]] const long long t0 = NOW();
     // curMap of the previous grow: drop its member flags from the cache (:519 starts from zeros)
     if (uni(g_ws[wave].members_cached)) {
@@ -366,7 +370,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 const uint32_t pk = lget(c, k2);
                 const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
                 const int slot = tile_slot(x >> 3, y >> 3);
-                if (g_ttag[wave][slot] == (y >> 3) * tilesX + (x >> 3)) g_tw[wave][slot * 64 + ((y & 7) << 3) + (x & 7)] &= ~2u;
+                if (g_ttag[wave][slot] == tile_key(x >> 3, y >> 3)) g_tw[wave][slot * 64 + ((y & 7) << 3) + (x & 7)] &= ~2u;
             }
         }
     }
@@ -424,34 +428,192 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
     unsigned long long flt_need = 0;                         // chunk [flt_base, flt_base + 64) of the worklist: entries to test in full
     int flt_base = 0;
     bool flt_valid = false;
+    int nxt_cnt = 0;                                         // entries of the next sweep's worklist
+    // One batch: up to 8 list entries (cnt of them, entry e of the batch = list index eidx in its 8 lanes) x 8 neighbours.
+    // Returns the number of entries it dealt with (1 instead of cnt when their tiles collide in the cache).
+    auto batch = [&](int cnt, const int eidx, const bool direct, const float Cf, const float Sf, const float rV, const float Vn,
+                     const float nrat) -> int {
+        bool valid = e < cnt;
+        uint32_t pk;
+        if (direct) pk = g_lst[wave][eidx];              // (entries past n: harmless garbage, masked by valid)
+        else pk = valid ? lget(c, eidx) : 0u;
+        const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+        bool inb = valid & ((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h);   // :536 (plain &: no short-circuit branches)
+        const int tx = nx >> 3, ty = ny >> 3;
+        const int slot = tile_slot(tx, ty);
+        const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
+        uint32_t word_r = g_tw[wave][cell];
+        const int tagv = g_ttag[wave][slot];
+        if (ballot64(inb & (tagv != tile_key(tx, ty)))) {
+            if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
+                cnt = 1;
+                valid = e < cnt;
+                inb = inb && valid;
+                ensure_tiles(c, inb, nx, ny);
+            }
+            word_r = g_tw[wave][cell];
+        }
+        const bool cand = inb & ((word_r & 3u) == 0u);   // :537: not in curMap, not banned (2 is growable, Q5)
+        const unsigned long long candm = ballot64(cand);
+        DSTAT(ST_BATCHES, 1);
+        if (candm) {
+            const int q = ny * w + nx;
+            const float af = __uint_as_float(word_r & ~3u);
+            float sf, cf;
+            fast_sincos(af, sf, cf);
+            // first occurrence of every candidate pixel: a lane is a repeat iff an EARLIER entry of the batch
+            // has the pixel in its 3x3 neighbourhood (that entry's lane for it comes first in reference order)
+            bool winner = cand;
+            if (cnt > 1) {
+                const int ex0 = (int)(pk & 0xffffu), ey0 = (int)(pk >> 16);
+                for (int e2 = 0; e2 + 1 < cnt; e2++) {
+                    const int px2 = __builtin_amdgcn_readlane(ex0, e2 * 8), py2 = __builtin_amdgcn_readlane(ey0, e2 * 8);
+                    winner = winner & !((e > e2) & ((unsigned)(nx - px2 + 1) <= 2u) & ((unsigned)(ny - py2 + 1) <= 2u));
+                }
+            }
+            unsigned long long gone = 0;                 // every lane whose pixel became a member in this batch
+            bool bulk = false;
+            float dot = 0.0f;
+            if (tol_small) {
+                const float m = (float)__builtin_popcountll(ballot64(winner));
+                dot = __builtin_fmaf(cf, Cf, sf * Sf);                            // ~ cos(distance) * |V|
+                const float eps_c = kEpsU * (1.0f + 2.1f * nrat) + 5e-6f;         // incl. the error of Vn
+                const float delta = m * turn * rV + 1e-7f;                        // |V| >= 1 here: accepted vectors only lengthen the sum
+                const float t_hi = delta <= tolf_lo ? (cos_tol + delta * sin_tol + eps_c) * Vn : 3e38f;
+                const float t_lo = delta <= 1.6f ? (cos_tol - delta * fminf(1.0f, sin_tol + delta) - eps_c) * Vn : -3e38f;
+                const unsigned long long pcm = ballot64(cand & (dot > t_hi));     // candidates that clearly pass
+                const unsigned long long failm = ballot64(cand & (dot < t_lo));   // ... clearly fail
+                bulk = (candm & ~(pcm | failm)) == 0ull;
+                if (bulk && pcm) {
+                    const unsigned long long P = ballot64(winner) & pcm;
+                    const int np = __builtin_popcountll(P);
+                    if ((P >> lane) & 1ull) {
+                        const int idx = n + mbcnt(P);
+                        g_tw[wave][cell] = word_r | 2u;                           // :549
+                        stamp[(uint32_t)q] = id;
+                        if (n + 64 <= LCAP) g_lst[wave][idx] = pack_xy(nx, ny);   // :551-556
+                        else lset(c, idx, pack_xy(nx, ny));
+                    }
+                    float ps = 0.0f, pc2 = 0.0f;
+                    unsigned long long todo = P;
+                    while (todo) {
+                        const int l = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        pc2 += rlf(cf, l); ps += rlf(sf, l);
+                    }
+                    Ce += (double)pc2; Se += (double)ps;
+                    n += np;
+                    g_ws[wave].dirty = 1;                // (all lanes, same value: see STAT)
+                    flt_valid = false;                   // the region angle moved
+                    gone = pcm;
+                }
+            }
+            if (!bulk) {
+                // ---- pixel by pixel, in reference order (lane order) ----
+                DSTAT(ST_SLOW, 1);
+                unsigned long long todo = candm;
+                while (todo) {
+                    const int l = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
+                    const float cl = rlf(cf, l), sl = rlf(sf, l);
+                    const float Cg = (float)Ce, Sg = (float)Se;
+                    const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
+                    const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
+                    int decided = -1;                    // 1 take, 0 reject, -1 exact test needed
+                    if (tol_small) {
+                        const float d1 = cl * Cg + sl * Sg;
+                        const float ec = kEpsU * (1.0f + 2.1f * nr) + 5e-6f;
+                        if (d1 > (cos_tol + ec) * Vg) decided = 1;
+                        else if (d1 < (cos_tol - ec) * Vg) decided = 0;
+                    } else if (Vg > 0.05f) {
+                        // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
+                        const double R = n == 1 ? regDeg0 : atan2(Se, Ce);
+                        const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
+                        const double al = (double)rlf(af, l);
+                        const double rw = fabs(R - al);
+                        const double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                        if (!(fabs(R) > kPi - er || fabs(df - tol) <= er || fabs(rw - kPi * 3 / 2.0) <= er)) decided = df < tol ? 1 : 0;
+                    }
+                    decided = uni(decided);              // (the same in every lane; computed on the vector unit)
+                    const int ql = __builtin_amdgcn_readlane(q, l);
+                    if (decided < 0) {
+                        exact_sums(c, n);
+                        const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
+                        DSTAT(ST_EXACT, 1);
+                        decided = uni(angle_diff(R, c.deg[ql]) < tol ? 1 : 0);              // :540-543
+                    }
+                    if (decided == 1) {
+                        if (lane == l) {
+                            g_tw[wave][cell] = word_r | 2u;                       // :549
+                            stamp[(uint32_t)q] = id;
+                            lset(c, n, pack_xy(nx, ny));                          // :551-556
+                        }
+                        Ce += (double)cl; Se += (double)sl;
+                        n++;
+                        g_ws[wave].dirty = 1;
+                        flt_valid = false;
+                        gone |= ballot64(cand & (q == ql));
+                    }
+                }
+            }
+            // entries that still have a growable non-member neighbour go to the next sweep's worklist
+            const unsigned long long left = candm & ~gone;
+            if (filter && left) {
+                const bool has = valid & (((left >> (8 * e)) & 0xffull) != 0ull);
+                if (tol_small) {
+                    // slack of this entry's remaining candidates: sin(distance - tol), from the start-of-batch estimate;
+                    // after a pixel-by-pixel batch the sum has moved in between, so no slack is claimed (0 = test in full next time)
+                    float sg = 2.0f;
+                    if ((left >> lane) & 1ull) {
+                        if (bulk) {
+                            const float ct = fminf(fmaxf(dot * rV, -1.0f), 1.0f);
+                            const float st = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
+                            const float cs_ = ct * cos_tol + st * sin_tol;            // cos(distance - tol)
+                            sg = cs_ <= 0.0f ? 1.0f : st * cos_tol - ct * sin_tol;    // sin(distance - tol), 1 beyond a quarter turn
+                        } else sg = 0.0f;
+                    }
+                    sg = min8(sg);
+                    if (has && k == 0 && eidx < mcap)
+                        meta[(uint32_t)eidx] = nf4{Cf * rV, Sf * rV, sg - 1.2e-4f - 8.0f * kEpsU * nrat, 0.0f};
+                }
+                const unsigned long long hm = ballot64(has & (k == 0));
+                const int add = __builtin_popcountll(hm);
+                const bool room = nxt_cnt + add <= LCAP && n <= 65535;
+                g_wl[wave][wcur ^ 1][(room & has & (k == 0)) ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
+                filter = filter && room;
+                nxt_cnt += room ? add : 0;
+            }
+        }
+        return cnt;
+    };
+    // The loop state is wave-uniform by construction, but the compiler's divergence analysis gives up on it as soon as the
+    // join of some lane-conditional store coincides with a join of the uniform control flow (which its CFG simplifications
+    // produce at will) -- and then runs the whole loop as divergent code on the vector unit.  Saying it again at the top of
+    // every iteration costs nothing where the analysis already knows, and keeps the control flow scalar where it does not.
+#define GROW_ESTIMATE()                                                                                                   \
+    n = uni(n); nxt_cnt = uni(nxt_cnt); filter = uni((int)filter) != 0;                                                 \
+    const float Cf = (float)Ce, Sf = (float)Se;                      /* the estimate of this batch (same in every lane) */ \
+    const float V2 = __builtin_fmaf(Cf, Cf, Sf * Sf);                                                                     \
+    const float rV = __builtin_amdgcn_rsqf(fmaxf(V2, 1e-12f)) * 1.000001f;   /* >= 1 / |V| */                             \
+    const float Vn = V2 * rV;                                                 /* |V| (to 2e-6) */                          \
+    const float nrat = (float)n * rV;                                         /* >= n / |V| */
     int sweep = 1, ex;
     do {                                                     // :525 sweeps to fixpoint (Q7)
         ex = n;
-        int nxt_cnt = 0;
-        const int n_start = (sweep == 1) ? 0 : n;            // entries below n_start come from the worklist
-        int wi = 0;                                          // worklist cursor
-        int i = (sweep == 1 || !filter) ? 0 : n_start;       // contiguous cursor
-        bool in_wl = (sweep > 1) && filter;
-        while (true) {
-            // The loop state is wave-uniform by construction, but the compiler's divergence analysis gives up on it as soon as
-            // the join of some lane-conditional store coincides with a join of the uniform control flow (which its CFG
-            // simplifications produce at will) -- and then runs the whole loop as divergent code on the vector unit.  Saying
-            // it again here costs nothing where the analysis already knows, and keeps the control flow scalar where it does not.
-            n = uni(n); i = uni(i); wi = uni(wi); nxt_cnt = uni(nxt_cnt); wl_cnt = uni(wl_cnt); flt_base = uni(flt_base);
-            in_wl = uni((int)in_wl) != 0; filter = uni((int)filter) != 0; flt_valid = uni((int)flt_valid) != 0;
-            flt_need = ((unsigned long long)(uint32_t)uni((int)(uint32_t)(flt_need >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)flt_need);
-            // ---- the estimate of this batch (same in every lane) ----
-            const float Cf = (float)Ce, Sf = (float)Se;
-            const float V2 = __builtin_fmaf(Cf, Cf, Sf * Sf);
-            const float rV = __builtin_amdgcn_rsqf(fmaxf(V2, 1e-12f)) * 1.000001f;   // >= 1 / |V|
-            const float Vn = V2 * rV;                                                 // |V| (to 2e-6)
-            const float nrat = (float)n * rV;                // >= n / |V|
-            // ---- pick up to 8 entries ----
-            int cnt, eidx;
-            if (in_wl) {
-                if (wi >= wl_cnt) { in_wl = false; continue; }
-                cnt = min(8, wl_cnt - wi);
-                if (tol_small && filter) {
+        nxt_cnt = 0;
+        int i = n;                                           // contiguous cursor: the entries appended during this sweep ...
+        if (sweep == 1 || !filter) i = 0;                    // ... or the whole list (first sweep; worklists given up)
+        else {
+            // ---- entries of earlier sweeps that still had a growable non-member neighbour ----
+            int wi = 0;                                      // worklist cursor
+            while (true) {
+                GROW_ESTIMATE();
+                wi = uni(wi); wl_cnt = uni(wl_cnt); flt_base = uni(flt_base); flt_valid = uni((int)flt_valid) != 0;
+                flt_need = ((unsigned long long)(uint32_t)uni((int)(uint32_t)(flt_need >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)flt_need);
+                if (wi >= wl_cnt) break;
+                int cnt = min(8, wl_cnt - wi);
+                if (tol_small && filter) {                   // (filter lost in this sweep: the rest of the worklist is tested in full)
                     if (!flt_valid || wi >= flt_base + 64) {
                         flt_base = wi;
                         bool nd = false;
@@ -486,164 +648,16 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                     const unsigned long long inv = ~rest;
                     cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
                 }
-                eidx = e < cnt ? (int)g_wl[wave][wcur][wi + e] : 0;
-            } else {
-                if (i >= n) break;                           // n is live (:529)
-                cnt = min(8, n - i);
-                eidx = i + e;
+                const int eidx = e < cnt ? (int)g_wl[wave][wcur][wi + e] : 0;
+                wi += batch(cnt, eidx, false, Cf, Sf, rV, Vn, nrat);
             }
-            bool valid = e < cnt;
-            uint32_t pk;
-            if (!in_wl && i + 8 <= LCAP) pk = g_lst[wave][eidx];              // (entries past n: harmless garbage, masked by valid)
-            else pk = valid ? lget(c, eidx) : 0u;
-            const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
-            bool inb = valid && (unsigned)nx < (unsigned)w && (unsigned)ny < (unsigned)h;   // :536
-            const int tx = nx >> 3, ty = ny >> 3;
-            const int slot = tile_slot(tx, ty);
-            const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
-            uint32_t word_r = g_tw[wave][cell];
-            if (ballot64(inb && g_ttag[wave][slot] != ty * tilesX + tx)) {
-                if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
-                    cnt = 1;
-                    valid = e < cnt;
-                    inb = inb && valid;
-                    ensure_tiles(c, inb, nx, ny);
-                }
-                word_r = g_tw[wave][cell];
-            }
-            const bool cand = inb && (word_r & 3u) == 0u;    // :537: not in curMap, not banned (2 is growable, Q5)
-            const unsigned long long candm = ballot64(cand);
-            DSTAT(ST_BATCHES, 1);
-            if (candm) {
-                const int q = ny * w + nx;
-                const float af = __uint_as_float(word_r & ~3u);
-                float sf, cf;
-                fast_sincos(af, sf, cf);
-                // first occurrence of every candidate pixel: a lane is a repeat iff an EARLIER entry of the batch
-                // has the pixel in its 3x3 neighbourhood (that entry's lane for it comes first in reference order)
-                bool winner = cand;
-                if (cnt > 1) {
-                    const int ex0 = (int)(pk & 0xffffu), ey0 = (int)(pk >> 16);
-                    for (int e2 = 0; e2 + 1 < cnt; e2++) {
-                        const int px2 = __builtin_amdgcn_readlane(ex0, e2 * 8), py2 = __builtin_amdgcn_readlane(ey0, e2 * 8);
-                        if (e > e2 && (unsigned)(nx - px2 + 1) <= 2u && (unsigned)(ny - py2 + 1) <= 2u) winner = false;
-                    }
-                }
-                unsigned long long gone = 0;                 // every lane whose pixel became a member in this batch
-                bool bulk = false;
-                float dot = 0.0f;
-                if (tol_small) {
-                    const float m = (float)__builtin_popcountll(ballot64(winner));
-                    dot = __builtin_fmaf(cf, Cf, sf * Sf);                            // ~ cos(distance) * |V|
-                    const float eps_c = kEpsU * (1.0f + 2.1f * nrat) + 5e-6f;         // incl. the error of Vn
-                    const float delta = m * turn * rV + 1e-7f;                        // |V| >= 1 here: accepted vectors only lengthen the sum
-                    const float t_hi = delta <= tolf_lo ? (cos_tol + delta * sin_tol + eps_c) * Vn : 3e38f;
-                    const float t_lo = delta <= 1.6f ? (cos_tol - delta * fminf(1.0f, sin_tol + delta) - eps_c) * Vn : -3e38f;
-                    const unsigned long long pcm = ballot64(cand && dot > t_hi);      // candidates that clearly pass
-                    const unsigned long long failm = ballot64(cand && dot < t_lo);    // ... clearly fail
-                    bulk = (candm & ~(pcm | failm)) == 0ull;
-                    if (bulk && pcm) {
-                        const unsigned long long P = ballot64(winner && ((pcm >> lane) & 1ull));
-                        const int np = __builtin_popcountll(P);
-                        if ((P >> lane) & 1ull) {
-                            const int idx = n + mbcnt(P);
-                            g_tw[wave][cell] = word_r | 2u;                           // :549
-                            stamp[(uint32_t)q] = id;
-                            if (n + 64 <= LCAP) g_lst[wave][idx] = pack_xy(nx, ny);   // :551-556
-                            else lset(c, idx, pack_xy(nx, ny));
-                        }
-                        float ps = 0.0f, pc2 = 0.0f;
-                        unsigned long long todo = P;
-                        while (todo) {
-                            const int l = __builtin_ctzll(todo);
-                            todo &= todo - 1ull;
-                            pc2 += rlf(cf, l); ps += rlf(sf, l);
-                        }
-                        Ce += (double)pc2; Se += (double)ps;
-                        n += np;
-                        g_ws[wave].dirty = 1;                // (all lanes, same value: see STAT)
-                        flt_valid = false;                   // the region angle moved
-                        gone = pcm;
-                    }
-                }
-                if (!bulk) {
-                    // ---- pixel by pixel, in reference order (lane order) ----
-                    DSTAT(ST_SLOW, 1);
-                    unsigned long long todo = candm;
-                    while (todo) {
-                        const int l = __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
-                        const float cl = rlf(cf, l), sl = rlf(sf, l);
-                        const float Cg = (float)Ce, Sg = (float)Se;
-                        const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
-                        const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
-                        int decided = -1;                    // 1 take, 0 reject, -1 exact test needed
-                        if (tol_small) {
-                            const float d1 = cl * Cg + sl * Sg;
-                            const float ec = kEpsU * (1.0f + 2.1f * nr) + 5e-6f;
-                            if (d1 > (cos_tol + ec) * Vg) decided = 1;
-                            else if (d1 < (cos_tol - ec) * Vg) decided = 0;
-                        } else if (Vg > 0.05f) {
-                            // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
-                            const double R = n == 1 ? regDeg0 : atan2(Se, Ce);
-                            const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
-                            const double al = (double)rlf(af, l);
-                            const double rw = fabs(R - al);
-                            const double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
-                            if (!(fabs(R) > kPi - er || fabs(df - tol) <= er || fabs(rw - kPi * 3 / 2.0) <= er)) decided = df < tol ? 1 : 0;
-                        }
-                        decided = uni(decided);              // (the same in every lane; computed on the vector unit)
-                        const int ql = __builtin_amdgcn_readlane(q, l);
-                        if (decided < 0) {
-                            exact_sums(c, n);
-                            const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
-                            DSTAT(ST_EXACT, 1);
-                            decided = uni(angle_diff(R, c.deg[ql]) < tol ? 1 : 0);              // :540-543
-                        }
-                        if (decided == 1) {
-                            if (lane == l) {
-                                g_tw[wave][cell] = word_r | 2u;                       // :549
-                                stamp[(uint32_t)q] = id;
-                                lset(c, n, pack_xy(nx, ny));                          // :551-556
-                            }
-                            Ce += (double)cl; Se += (double)sl;
-                            n++;
-                            g_ws[wave].dirty = 1;
-                            flt_valid = false;
-                            gone |= ballot64(cand && q == ql);
-                        }
-                    }
-                }
-                // entries that still have a growable non-member neighbour go to the next sweep's worklist
-                const unsigned long long left = candm & ~gone;
-                if (filter && left) {
-                    const bool has = valid && ((left >> (8 * e)) & 0xffull) != 0ull;
-                    if (tol_small) {
-                        // slack of this entry's remaining candidates: sin(distance - tol), from the start-of-batch estimate;
-                        // after a pixel-by-pixel batch the sum has moved in between, so no slack is claimed (0 = test in full next time)
-                        float sg = 2.0f;
-                        if ((left >> lane) & 1ull) {
-                            if (bulk) {
-                                const float ct = fminf(fmaxf(dot * rV, -1.0f), 1.0f);
-                                const float st = __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
-                                const float cs_ = ct * cos_tol + st * sin_tol;            // cos(distance - tol)
-                                sg = cs_ <= 0.0f ? 1.0f : st * cos_tol - ct * sin_tol;    // sin(distance - tol), 1 beyond a quarter turn
-                            } else sg = 0.0f;
-                        }
-                        sg = min8(sg);
-                        if (has && k == 0 && eidx < mcap)
-                            meta[(uint32_t)eidx] = nf4{Cf * rV, Sf * rV, sg - 1.2e-4f - 8.0f * kEpsU * nrat, 0.0f};
-                    }
-                    const unsigned long long hm = ballot64(has && k == 0);
-                    const int add = __builtin_popcountll(hm);
-                    const bool room = nxt_cnt + add <= LCAP && n <= 65535;
-                    g_wl[wave][wcur ^ 1][room && has && k == 0 ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
-                    filter = filter && room;
-                    nxt_cnt += room ? add : 0;
-                }
-            }
-            if (in_wl) wi += cnt; else i += cnt;
+        }
+        while (true) {                                       // ---- contiguous entries; n is live (:529) ----
+            GROW_ESTIMATE();
+            i = uni(i);
+            if (i >= n) break;
+            const int cnt = min(8, n - i);
+            i += batch(cnt, i + e, i + 8 <= LCAP, Cf, Sf, rV, Vn, nrat);
         }
         wcur ^= 1;
         wl_cnt = nxt_cnt;
@@ -651,6 +665,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
         flt_valid = false;
         if (n != ex) wg_fence();                             // meta[] written in this sweep is read in the next
     } while (n != ex);
+#undef GROW_ESTIMATE
     if (lane == 0) g_ws[wave].gnum = n;
     STAT(ST_GROW, 1);
     STAT(ST_GROWN, n);
@@ -777,10 +792,79 @@ __device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, 
     const double rad1 = sqrt(ax * ax + ay * ay), rad2 = sqrt(bx * bx + by * by);    // :768-769
     double rad = rad1 > rad2 ? rad1 : rad2;
     bool removed_any = false;
+    const int wave = __builtin_amdgcn_readfirstlane(c.wave);
+    unsigned long long* const msk = reinterpret_cast<unsigned long long*>(g_acc[wave]);   // keep-masks of up to 128 chunks of 64 entries
+    uint32_t* const mv = reinterpret_cast<uint32_t*>(&g_wl[wave][0][0]);                   // up to 1024 moved entries (the worklists are free here)
     while (den < denThre) {                                                        // :775
         rad *= 0.75;
         STAT(ST_RRRPASS, 1);
-        int i = 0;
+        num = __builtin_amdgcn_readfirstlane(num);
+        // The reference walks the list from the front and fills every slot whose point is farther than rad with the LAST
+        // point of the list, re-testing it (:779-789).  The outcome is: the K points within rad stay in slots [0, K); the
+        // holes among those slots (ascending) receive the kept points of the slots >= K, taken from the back (descending).
+        // That is computed 64 entries at a time; lists too long for the scratch arrays take the reference's own loop below.
+        const int nchunks = (num + 63) >> 6;
+        bool parallel = nchunks <= 128;
+        int K = 0;
+        if (parallel) {
+            for (int ci = 0; ci < nchunks; ci++) {
+                const int idx = ci * 64 + lane;
+                const bool valid = idx < num;
+                const uint32_t pkx = valid ? lget(c, idx) : 0u;
+                const int px = (int)(pkx & 0xffffu), py = (int)(pkx >> 16);
+                const double ddx = sx - px, ddy = sy - py;
+                const bool far = valid & (sqrt(ddx * ddx + ddy * ddy) > rad);      // :780
+                const unsigned long long nearm = ballot64(valid & !far);
+                msk[ci] = nearm;                           // (all lanes, same value)
+                K += __builtin_popcountll(nearm);
+            }
+            if (min(K, num - K) > 1024) parallel = false;  // more moves than mv[] holds
+        }
+        if (parallel) {
+            if (K != num) {
+                int nm = 0;                                // kept points of the slots >= K, highest slot first
+                for (int ci = nchunks - 1; ci >= 0 && ci * 64 + 63 >= K; ci--) {
+                    const int idx = ci * 64 + lane;
+                    const bool is = (((msk[ci] >> lane) & 1ull) != 0ull) & (idx >= K);
+                    const unsigned long long mm = ballot64(is);
+                    const int above = __builtin_popcountll((mm >> lane) >> 1);
+                    mv[is ? nm + above : 1024] = is ? lget(c, idx) : 0u;           // (no branch: dummy slot; g_wl has 2 spare entries = 1 word)
+                    nm += __builtin_popcountll(mm);
+                }
+                int nh = 0;                                // far points of the slots < K, lowest slot first
+                for (int ci = 0; ci * 64 < K; ci++) {
+                    const int idx = ci * 64 + lane;
+                    const bool valid = idx < num;
+                    const bool nearb = ((msk[ci] >> lane) & 1ull) != 0ull;
+                    const unsigned long long hm = ballot64((idx < K) & !nearb);
+                    const uint32_t old = valid ? lget(c, idx) : 0u;
+                    if (valid & !nearb) c.stamp[(size_t)(old >> 16) * w + (old & 0xffffu)] = 0u;   // curMap = 0 (:781), every far point of this chunk
+                    if ((idx < K) & !nearb) lset(c, idx, mv[nh + mbcnt(hm)]);                      // :782-785
+                    nh += __builtin_popcountll(hm);
+                }
+                for (int ci = (K + 63) >> 6; ci < nchunks; ci++) {                                 // far points of the chunks wholly behind K
+                    const int idx = ci * 64 + lane;
+                    if ((idx < num) & (((msk[ci] >> lane) & 1ull) == 0ull)) {
+                        const uint32_t old = lget(c, idx);
+                        c.stamp[(size_t)(old >> 16) * w + (old & 0xffffu)] = 0u;
+                    }
+                }
+                num = K;
+                removed_any = true;
+            }
+            // the extra round at i == num (:779 `<=`): the slot holds the NULL written at :784-785, i.e. the point (0, 0)
+            if (!removed_any) STAT(ST_OOB, 1);             // the reference reads out of bounds here (UB): no removal
+            else {
+                const double ddx = sx, ddy = sy;
+                if (sqrt(ddx * ddx + ddy * ddy) > rad) {
+                    c.stamp[0] = 0u;                       // curMap(0, 0) = 0
+                    num--;                                 // the last point is dropped from the list (its curMap bit stays)
+                    STAT(ST_SENT, 1);
+                }
+            }
+            wg_fence();
+        }
+        int i = parallel ? num + 1 : 0;
         while (i <= num) {                                                         // :779 (`<=`)
             int px, py;
             if (i == num) {
