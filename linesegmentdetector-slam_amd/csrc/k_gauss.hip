@@ -29,7 +29,7 @@ __device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 
 // column's taps in registers and both passes are fully unrolled.  HS == 0: any tap count.
 template <int HS>
 __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
-                                              const double* __restrict__ taps_g, int W, int H, int w, int h,
+                                              const double* __restrict__ taps_g, int W, int H, int w, int h, int gp,
                                               double sca, int tapR, int IWp, int IHmax) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int hSize = HS > 0 ? HS : 2 * tapR + 1;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
     const size_t img = blockIdx.z;
     const uint8_t* src = in + img * (size_t)W * H;
-    double* dst = out + img * (size_t)w * h;
+    double* dst = out + img * (size_t)gp * h;                     // rows padded to gp doubles (128-byte aligned rows for K2)
 
     const int Xl = min(X0 + TW - 1, w - 1), Yl = min(Y0 + TH - 1, h - 1);
     const int c0 = centre_of(X0, sca) - tapR, c1 = centre_of(Xl, sca) + tapR;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
             } else {
                 for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
             }
-            dst[(size_t)gY * w + gX] = v;
+            dst[(size_t)gY * gp + gX] = v;
         }
     }
 }
@@ -194,7 +194,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((g.w + TW - 1) / TW, (g.h + TH - 1) / TH, n);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.sca, g.tapR, IWp, IHmax);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.gp, g.sca, g.tapR, IWp, IHmax);
 }
 
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {

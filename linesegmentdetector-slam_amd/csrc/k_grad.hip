@@ -21,31 +21,67 @@ __device__ __forceinline__ uint32_t pack_pw(double d, uint32_t code) {
 // One 64-lane workgroup owns a 64-column x 8-row strip.  Each lane walks its column downwards keeping the row
 // above in registers; the left neighbour comes from the adjacent lane (lane 0 loads it), so every gauss value is
 // fetched from HBM once per strip (+1/8 for the row above the strip, +1/64 for the column left of it) with fully
-// coalesced 512-byte rows and no LDS staging.
-// Two phases so that the expensive, correctly rounded atan2 / sincos (devmath.h) never run in a half-empty
-// wavefront: phase 1 does the dense part (gradient, magnitude, threshold, max, and the angle of the ~93 %
-// zero-gradient pixels) and pushes the indices of the non-zero-gradient pixels of the strip into an LDS list;
-// phase 2 walks that list with all lanes busy.
+// coalesced 512-byte rows and no LDS staging.  The Gaussian image comes with a row pitch of gp doubles (a multiple of
+// 16): every 512-byte row segment a wavefront loads covers exactly four 128-byte lines.
+// Three phases so that the expensive, correctly rounded atan2 / sincos (devmath.h) never run in a half-empty
+// wavefront and every map is stored in whole coalesced rows:
+//   1  the dense part: gradient, magnitude (stored), threshold, max, and the angle of the ~93 % zero-gradient pixels,
+//      kept in registers; the non-zero-gradient pixels of the strip go into an LDS list (index + gradient);
+//   2  the list, all lanes busy: angle (left in the list slot) and, where the pixel stays growable, (sin, cos) -- the only
+//      scattered store; every lane then picks the angles of its own pixels out of the list;
+//   3  angle map and packed pixel words, whole rows from registers.
+// (The list holds CAP entries; a strip with more non-zero gradients runs phase 2 in between.)
+// Measured alternatives, all slower: a workgroup walking the whole width or a whole column band (fewer
+// partly written lines / better filled phase 2, but too few independent loads in flight), with and without loads one step ahead.
+constexpr int CAP = 256;
+
 __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gauss, double* __restrict__ mag,
                                                  double* __restrict__ deg, double2* __restrict__ sc,
                                                  uint32_t* __restrict__ pw,
-                                                 unsigned long long* __restrict__ maxbits, int w, int h,
+                                                 unsigned long long* __restrict__ maxbits, int w, int h, int gp,
                                                  double gradThre) {
-    __shared__ uint32_t l_px[GX * GR];       // (strip-local pixel index << 1) | growable
+    __shared__ uint32_t l_px[CAP];           // (strip-local pixel index << 1) | growable
+    __shared__ double2 l_g[CAP];             // in: (gradX, gradY) of the listed pixel; out: (angle, -)
     const size_t img = blockIdx.z;
     const size_t base = img * (size_t)w * h;
+    const double* __restrict__ gim = gauss + img * (size_t)gp * h;
     const int lane = threadIdx.x;
     const int x = blockIdx.x * GX + lane, y0 = blockIdx.y * GR;
     const bool colok = x < w;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     int cnt = 0;                                               // entries in the LDS list (wave-uniform)
     double mx = 0;
+    double rowD[GR];                                           // angle of this lane's pixel in row r ...
+    uint32_t rowU[GR];                                         // ... its usedMap code ...
+    int rowSlot[GR];                                           // ... and, while the angle is still to come, its list slot (else -1)
+
+    auto flush = [&]() {
+        // phase 2: level-line angle (+ sin/cos where the pixel stays growable) of the listed pixels
+        for (int i = lane; i < cnt; i += GX) {
+            const uint32_t e = l_px[i];
+            const double2 gr = l_g[i];
+            double d = atan2_g(gr.x, -gr.y);                   // :169
+            if (fabs(d - kPi) < 0.000001) d = 0;               // :170-171
+            l_g[i] = make_double2(d, 0.0);
+            if (e & 1u) {                                      // sin/cos(deg) for RegionGrower (:545-546)
+                const int lt = (int)(e >> 1);
+                const size_t p = base + (size_t)(y0 + lt / GX) * w + (blockIdx.x * GX + lt % GX);
+                double sv, cv;
+                sincos_g(d, sv, cv);
+                sc[p] = make_double2(sv, cv);
+            }
+        }
+        #pragma unroll
+        for (int r = 0; r < GR; r++)
+            if (rowSlot[r] >= 0) { rowD[r] = l_g[rowSlot[r]].x; rowSlot[r] = -1; }
+        cnt = 0;
+    };
 
     // row above the strip: C = G[y-1][x], D = G[y-1][x-1]
     double up = 0, upl = 0;
     if (y0 >= 1 && colok) {
-        up = gauss[base + (size_t)(y0 - 1) * w + x];
-        if (lane == 0 && x >= 1) upl = gauss[base + (size_t)(y0 - 1) * w + x - 1];
+        up = gim[(size_t)(y0 - 1) * gp + x];
+        if (lane == 0 && x >= 1) upl = gim[(size_t)(y0 - 1) * gp + x - 1];
     }
     {
         const double t = __shfl_up(up, 1);
@@ -58,14 +94,15 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
         const int y = y0 + r;
         rowA[r] = 0; rowB0[r] = 0;
         if (colok && y < h) {
-            rowA[r] = gauss[base + (size_t)y * w + x];
-            if (lane == 0 && x >= 1) rowB0[r] = gauss[base + (size_t)y * w + x - 1];
+            rowA[r] = gim[(size_t)y * gp + x];
+            if (lane == 0 && x >= 1) rowB0[r] = gim[(size_t)y * gp + x - 1];
         }
     }
     #pragma unroll
     for (int r = 0; r < GR; r++) {
         const int y = y0 + r;
-        if (y >= h) break;
+        rowD[r] = 0; rowU[r] = 0; rowSlot[r] = -1;
+        if (y >= h) continue;
         const double A = rowA[r];
         double B = rowB0[r];
         {
@@ -90,20 +127,20 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
         if (colok) {
             const size_t p = base + (size_t)y * w + x;
             mag[p] = m;
-            if (!heavy) {
-                deg[p] = d;
-                pw[p] = pack_pw(d, u);
-                if (u == 0) sc[p] = make_double2(0.0, 1.0);    // row 0 / col 0: angle 0 exactly, growable (Q3)
-            }
+            if (!heavy && u == 0) sc[p] = make_double2(0.0, 1.0);   // row 0 / col 0: angle 0 exactly, growable (Q3)
         }
+        rowD[r] = d; rowU[r] = u;
         const unsigned long long hm = __ballot(heavy);
         if (heavy) {
             const int slot = cnt + __builtin_popcountll(hm & ltmask);
             l_px[slot] = ((uint32_t)(r * GX + lane) << 1) | (u == 0 ? 1u : 0u);
+            l_g[slot] = make_double2(gradX, gradY);
+            rowSlot[r] = slot;
         }
         cnt += __builtin_popcountll(hm);
         mx = fmax(mx, m);
         up = A; upl = B;
+        if (cnt > CAP - GX) flush();                           // (the next row may add up to GX entries)
     }
     // per-image max (myLSD.cpp:167-168): non-negative doubles order like their bit patterns
     unsigned long long bits = (unsigned long long)__double_as_longlong(mx);
@@ -113,29 +150,24 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
     }
     if (lane == 0 && bits != 0ull) atomicMax(&maxbits[img], bits);
 
-    // phase 2: level-line angle (+ sin/cos where the pixel stays growable) of the non-zero-gradient pixels
-    for (int i = lane; i < cnt; i += GX) {
-        const uint32_t e = l_px[i];
-        const int lt = (int)(e >> 1);
-        const size_t p = base + (size_t)(y0 + lt / GX) * w + (blockIdx.x * GX + lt % GX);
-        // the 2x2 stencil again (L2-resident: this strip has just been read); same expressions, same bits
-        const double A = gauss[p], B = gauss[p - 1], C = gauss[p - w], D = gauss[p - w - 1];
-        const double gradX = (B + D - A - C) / 2.0, gradY = (C + D - A - B) / 2.0;
-        double d = atan2_g(gradX, -gradY);                     // :169
-        if (fabs(d - kPi) < 0.000001) d = 0;                   // :170-171
-        deg[p] = d;
-        pw[p] = pack_pw(d, (e & 1u) ? kPwFree : kPwStatic);
-        if (e & 1u) {                                          // sin/cos(deg) for RegionGrower (:545-546)
-            double sv, cv;
-            sincos_g(d, sv, cv);
-            sc[p] = make_double2(sv, cv);
+    flush();
+    // phase 3: degMap and the packed pixel words, whole rows
+    if (colok) {
+        #pragma unroll
+        for (int r = 0; r < GR; r++) {
+            const int y = y0 + r;
+            if (y < h) {
+                const size_t p = base + (size_t)y * w + x;
+                deg[p] = rowD[r];
+                pw[p] = pack_pw(rowD[r], rowU[r]);
+            }
         }
     }
 }
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     dim3 grid((g.w + GX - 1) / GX, (g.h + GR - 1) / GR, n);
-    hipLaunchKernelGGL(k_gradient, grid, dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits, g.w, g.h,
+    hipLaunchKernelGGL(k_gradient, grid, dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits, g.w, g.h, g.gp,
                        g.gradThre);
 }
 

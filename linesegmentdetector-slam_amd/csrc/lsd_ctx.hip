@@ -25,6 +25,7 @@ struct lsd_ctx {
     hipStream_t last_stream = nullptr; // stream of the last enqueue
     std::string err;
     // workspace capacity
+    size_t cap_gpx = 0;                                      // Gaussian elements per image (rows padded to Geom::gp)
     size_t cap_n = 0, cap_npx = 0, cap_wh = 0, cap_ws = 0;   // images, scaled pixels per image, input pixels per image, wave slots
     int cap_max_lines = 0;
     bool cap_trace = false;
@@ -142,6 +143,7 @@ static int make_geom(const lsd_params* p, int cols, int rows, Geom* g) {
     if (g->w > 32766 || g->h > 32766) return LSD_ERR_UNSUPPORTED;
     if ((long long)g->w * g->h > (1ll << 30)) return LSD_ERR_UNSUPPORTED;
     g->npx = g->w * g->h;
+    g->gp = (g->w + 15) & ~15;
     g->sca = p->sca;
     g->tapR = tap_radius(p->sca, p->sig);
     if (g->tapR < 0 || g->tapR > kMaxTapRadius) return LSD_ERR_UNSUPPORTED;
@@ -198,15 +200,16 @@ static int waves_for(const lsd_ctx* c, int n) {
     return 4;
 }
 
-static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
+static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
     const size_t need_ws = n * (size_t)waves_for(c, (int)n);       // per-wave arrays: wave slots of the whole batch
-    const bool grow_main = n > c->cap_n || npx > c->cap_npx || need_ws > c->cap_ws;
+    const bool grow_main = n > c->cap_n || npx > c->cap_npx || gpx > c->cap_gpx || need_ws > c->cap_ws;
     if (grow_main) {
         const size_t nn = n > c->cap_n ? n : c->cap_n, pp = npx > c->cap_npx ? npx : c->cap_npx;
+        const size_t gg = gpx > c->cap_gpx ? gpx : c->cap_gpx;
         const size_t ws = need_ws > c->cap_ws ? need_ws : c->cap_ws;
         HIPCHK(c, hipDeviceSynchronize());
         const size_t tot = nn * pp;
-        HIPCHK(c, re_alloc(&c->gauss, tot)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
+        HIPCHK(c, re_alloc(&c->gauss, nn * gg)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
         HIPCHK(c, re_alloc(&c->sc, tot));
         HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
@@ -221,7 +224,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, in
         HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
-        c->cap_n = nn; c->cap_npx = pp; c->cap_ws = ws;
+        c->cap_n = nn; c->cap_npx = pp; c->cap_gpx = gg; c->cap_ws = ws;
     }
     if (max_lines > c->cap_max_lines) {
         HIPCHK(c, hipDeviceSynchronize());
@@ -234,14 +237,13 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t wh, in
         HIPCHK(c, hipMalloc(&c->seeds, c->cap_n * c->cap_npx * sizeof(SeedRec)));
         c->cap_trace = true;
     }
-    (void)wh;
     return LSD_OK;
 }
 
 // A failed (re)allocation leaves some arrays freed and others at their old size: forget the whole workspace, so that the next
 // call starts from nothing instead of trusting stale capacities.
-static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max_lines, bool trace) {
-    const int st = ensure_workspace_impl(c, n, npx, wh, max_lines, trace);
+static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
+    const int st = ensure_workspace_impl(c, n, npx, gpx, max_lines, trace);
     if (st != LSD_OK) {
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
@@ -250,7 +252,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t wh, int max
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
-        c->cap_n = c->cap_npx = c->cap_ws = 0; c->cap_max_lines = 0; c->cap_trace = false;
+        c->cap_n = c->cap_npx = c->cap_gpx = c->cap_ws = 0; c->cap_max_lines = 0; c->cap_trace = false;
     }
     return st;
 }
@@ -349,7 +351,7 @@ int lsd_reserve(lsd_ctx* c, int n, int cols, int rows) {
     int st = make_geom(&p, cols, rows, &g);
     if (st != LSD_OK) return st;
     HIPCHK(c, hipSetDevice(c->device));
-    return ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)cols * rows, c->cap_max_lines, c->trace);
+    return ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)g.gp * g.h, c->cap_max_lines, c->trace);
 }
 
 int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int rows, const lsd_params* p,
@@ -361,7 +363,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     if (st != LSD_OK) return st;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
-    st = ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)cols * rows, max_lines, c->trace);
+    st = ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)g.gp * g.h, max_lines, c->trace);
     if (st != LSD_OK) return st;
     st = ensure_tables(c, p, g, s);
     if (st != LSD_OK) return st;
@@ -520,7 +522,11 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
     size_t need = 0;
     int32_t nbv = 0, cnt = 0, nseed = 0;
     switch (what) {
-        case LSD_DBG_GAUSS: src = c->gauss + off; need = npx * 8; break;
+        case LSD_DBG_GAUSS:                                           // (rows are padded to gp doubles on the device)
+            if (bytes < npx * 8) return LSD_ERR_INVALID;
+            HIPCHK(c, hipMemcpy2D(out, (size_t)c->geom.w * 8, c->gauss + (size_t)image * c->geom.gp * c->geom.h, (size_t)c->geom.gp * 8,
+                                  (size_t)c->geom.w * 8, (size_t)c->geom.h, hipMemcpyDeviceToHost));
+            return LSD_OK;
         case LSD_DBG_MAG: src = c->mag + off; need = npx * 8; break;
         case LSD_DBG_DEG: src = c->deg + off; need = npx * 8; break;
         case LSD_DBG_STATE: src = c->pw + off; need = npx * 4; break;

@@ -17,6 +17,7 @@ struct Geom {
     int W, H;            // original size
     int w, h;            // scaled size
     int npx;             // w*h
+    int gp;              // row pitch (doubles) of the Gaussian image: w rounded up to 16, so that every row starts on a 128-byte line
     double sca;
     int tapR;            // Gaussian tap radius h (myLSD.cpp:393)
     int pseBin;
@@ -40,7 +41,7 @@ __host__ __device__ inline uint32_t pw_used(uint32_t w) { return (w & 3u) == 3u 
 struct Buffers {
     const uint8_t* in;     // n x H x W (pitch W)
     uint8_t* in_rw;        // same pointer when write-back of the remap is requested, else null
-    double* gauss;         // n x npx
+    double* gauss;         // n x h x gp (row pitch gp: see Geom)
     double* mag;           // n x npx
     double* deg;           // n x npx
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass

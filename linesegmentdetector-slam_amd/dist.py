@@ -3,8 +3,9 @@ torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU t
 collective on the data path.  The only exchange is the result hand-off the reference's consumer
 needs in one place: the ragged line lists are gathered to one rank:
 
-    1. all_gather of the int32 per-image line counts (tiny, fixed size);
-    2. gather of each rank's compacted lines, padded to the largest rank total.
+    1. all_gather of the per-image line counts (tiny, fixed size);
+    2. gather of each rank's compacted lines in a fixed-capacity slab (regular collective, no host
+       synchronisation in the per-step path).
 
 lsd_line is moved as 10 x int64 words per line (a byte copy: no float canonicalisation on the way).
 """
@@ -30,45 +31,72 @@ def compact_lines(lines_i64, counts):
     return lines_i64[mask], c
 
 
-def gather_line_lists(lines_i64, counts, n_total, dst=0, group=None):
+def pack_lines(lines_i64, counts, cap_rows):
+    """[n, max_lines, 10] int64 + [n] int32 -> ([cap_rows, 10] int64 with image i's lines at rows [off[i], off[i] + c[i]),
+    c int64[n], overflow bool[1]) -- all on the device, no host synchronisation (rows that do not fit go to a dump row)."""
+    n, max_lines, _ = lines_i64.shape
+    dev = lines_i64.device
+    c = counts.clamp(max=max_lines).to(torch.int64)
+    off = torch.cumsum(c, 0) - c
+    k = torch.arange(max_lines, device=dev)[None, :]
+    dest = off[:, None] + k
+    dest = torch.where((k < c[:, None]) & (dest < cap_rows), dest, torch.full_like(dest, cap_rows))
+    payload = torch.zeros((cap_rows + 1, WORDS_PER_LINE), dtype=torch.int64, device=dev)
+    payload[dest.reshape(-1)] = lines_i64.reshape(-1, WORDS_PER_LINE)
+    return payload[:cap_rows], c, (c.sum() > cap_rows).reshape(1)
+
+
+def gather_line_lists(lines_i64, counts, n_total, dst=0, group=None, cap_rows=None, dense=True):
     """Gathers every rank's line lists to `dst`.
 
     lines_i64 [n_local, max_lines, 10] int64, counts [n_local] int32 for this rank's shard
-    (shard_range(n_total, world, rank)).  Returns on dst: (offsets int64[n_total+1], lines int64[total,10])
-    in global image order; on other ranks (None, None)."""
+    (shard_range(n_total, world, rank)).  Two regular collectives and NO host synchronisation on any rank:
+      1. all_gather of the per-image counts (padded to the largest shard);
+      2. gather of a fixed-capacity slab of cap_rows lines per rank (default: the largest shard x max_lines, which cannot
+         overflow; a smaller cap_rows keeps the slab near the payload -- an overflow is flagged, never silent).
+    dense=False (the per-step path): returns on dst the device tensors (counts int64[world, per], lines int64[world, cap_rows, 10],
+    overflow bool[world]); rank r's lines sit compacted at the head of lines[r] in image order.  dense=True additionally trims them
+    on dst into (offsets int64[n_total+1], lines int64[total, 10]) in global image order -- this needs the totals on the
+    host, i.e. one synchronisation on dst only, after both collectives.  Other ranks get (None, None[, None])."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_range(n_total, world, rank)
     assert counts.numel() == hi - lo, (counts.numel(), lo, hi)
     dev = lines_i64.device
     per = max(shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world))
-    dense, c = compact_lines(lines_i64, counts)
-    # step 1: counts (padded to the largest shard so the all-gather is regular)
-    cpad = torch.zeros(per, dtype=torch.int64, device=dev)
+    if cap_rows is None:
+        cap_rows = max(per * lines_i64.shape[1], 1)
+    payload, c, over = pack_lines(lines_i64, counts, cap_rows)
+    # step 1: counts (padded to the largest shard so the all-gather is regular) + the overflow flags
+    cpad = torch.zeros(per + 1, dtype=torch.int64, device=dev)
     cpad[:hi - lo] = c
-    allc = torch.empty(world * per, dtype=torch.int64, device=dev)
+    cpad[per] = over.to(torch.int64)[0]
+    allc = torch.empty(world * (per + 1), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allc, cpad, group=group)
-    allc = allc.view(world, per).cpu()
-    totals = allc.sum(1)
-    pad_rows = int(totals.max().item())
-    # step 2: payload, padded to the largest rank total
-    payload = torch.zeros((max(pad_rows, 1), WORDS_PER_LINE), dtype=torch.int64, device=dev)
-    payload[:dense.shape[0]] = dense
+    allc = allc.view(world, per + 1)
+    # step 2: the fixed-capacity slabs
     if rank == dst:
         bufs = [torch.empty_like(payload) for _ in range(world)]
         dist.gather(payload, bufs, dst=dst, group=group)
+        slabs = torch.stack(bufs, 0)
+        if not dense:
+            return allc[:, :per], slabs, allc[:, per] != 0
+        hc = allc.cpu()                                    # (dst only, after the collectives)
+        if bool((hc[:, per] != 0).any()):
+            raise RuntimeError("gather_line_lists: a rank produced more than cap_rows=%d lines" % cap_rows)
         parts, cnts = [], []
         for r in range(world):
             rlo, rhi = shard_range(n_total, world, r)
-            parts.append(bufs[r][:int(totals[r])])
-            cnts.append(allc[r, :rhi - rlo])
+            cr = hc[r, :rhi - rlo]
+            parts.append(slabs[r, :int(cr.sum())])
+            cnts.append(cr)
         lines = torch.cat(parts, 0)
         cnt = torch.cat(cnts)
         offsets = torch.zeros(n_total + 1, dtype=torch.int64)
         offsets[1:] = torch.cumsum(cnt, 0)
         return offsets, lines
     dist.gather(payload, None, dst=dst, group=group)
-    return None, None
+    return (None, None) if dense else (None, None, None)
 
 
 def lines_to_numpy(lines_i64, line_dtype):
