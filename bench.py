@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark: whole-pipeline LSD throughput (Mpixels/s and lines/s) on a batch of
-512 synthetic 2048x2048 occupancy maps per GPU (BASELINE.json configs[3]/[4], SURVEY 8d "C4").
+512 synthetic 2048x2048 occupancy maps (BASELINE.json configs[3]/[4], SURVEY 8d "C4").
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--scaling strong]
 
 One process per GPU.  A "step" is one pass of the hot path (remap -> Gaussian -> gradient -> sort -> region
-grow/rectangle/NFA -> line list + raster) over this rank's 512-image batch, inputs resident in HBM.  Images
-are independent, so ranks never exchange data on the path (weak scaling: 512 images per GPU); for N > 1 each
-step ends with the RCCL gather of the ragged line lists to rank 0.  Rank 0 prints ONE JSON line.
+grow/rectangle/NFA -> line list + raster) over this rank's images, inputs resident in HBM.  Images are independent, so
+ranks never exchange data on the path; for N > 1 each step ends with the RCCL gather of the ragged line lists to
+rank 0 -- two regular collectives, no host synchronisation.
+  --scaling weak   (default; what the driver's N = 1 line and its scaling curve use): every GPU gets its own --batch images;
+  --scaling strong (BASELINE configs[4] as written): the SAME --batch images are split over the ranks, contiguous shards.
+Rank 0 prints ONE JSON line.  Outside the timed region (N = 1, unless --no-cpu-baseline): the targets north_star names on
+mapValue_map1 (512 x replicated map1 -> lines/s; one host-ABI call createMapCache + myLineSegmentDetector), the
+single-image latency, the device copy ceiling and the CPU baseline (SURVEY 8d protocol).
 """
 import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,7 +32,10 @@ if ROOT not in sys.path:
 
 SOURCES = ["aisle1", "aisle2", "aisle3", "mapValue"]   # the four aisle-class fixtures
 HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-GRAD_BYTES_PER_PX = 25.0                                # 8 B read + 8+8+1 B written per scaled pixel
+GRAD_BYTES_PER_PX = 25.0                                # K2: 8 B read + 8+8+1 B written per scaled pixel
+# the unmodified reference, single thread, survey container (it cannot be built on the GPU box)
+REF_MAP1 = {"ms": 5.20, "lines_per_s": 1346.0, "Mpix_per_s": 56.1}
+REF_TILE2048 = {"ms": 1362.0, "lines_per_s": 175.0, "Mpix_per_s": 3.1}
 
 
 def make_image(maps, i, size):
@@ -60,23 +69,67 @@ def load_maps():
     return {k: z[k] for k in z.files}
 
 
-def cpu_baseline(maps, size, first, budget_s=15.0, max_images=512):
-    """The CPU oracle (a single-threaded port of the reference path) on a bounded sample of the SAME workload."""
+# ---- CPU baseline: the oracle = a single-threaded port of the reference path, on the GPU box's host cores ----
+def _cpu_worker(args):
+    """One pinned single-thread oracle instance over its own slice of the batch (the reference has no intra-image threading)."""
+    core, first, count, size, reps = args
+    try:
+        os.sched_setaffinity(0, {core})
+    except (AttributeError, OSError):
+        pass
+    from oracle import oracle
+    maps = load_maps()
+    oracle.lsd(maps["map1"].copy())                                 # warm-up
+    imgs = [make_image(maps, first + k, size) for k in range(count)]
+    times, nl = [], 0
+    for rep in range(reps + 1):                                     # 1 warm-up pass + reps timed passes over the sample
+        t0 = time.perf_counter()
+        nl = 0
+        for im in imgs:
+            nl += len(oracle.lsd(im.copy(), want_lineim=True)["lines"])
+        if rep:
+            times.append(time.perf_counter() - t0)
+    return times, nl
+
+
+def cpu_baseline(size, first, sample=24, reps=5):
     from oracle import oracle
     oracle.build()
-    oracle.lsd(maps["map1"].copy())   # warm-up
-    t_used, px, nl, k = 0.0, 0, 0, 0
-    while k < max_images and t_used < budget_s:
-        img = make_image(maps, first + k, size)
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    times, nl = _cpu_worker((cores[0], first, sample, size, reps))  # one pinned core: min and median of `reps` passes
+    px = sample * size * size / 1e6
+    tmin, tmed = min(times), statistics.median(times)
+    out = {"value": px / tmin, "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "images %d..%d of the same %dx%d batch, oracle/lsd_oracle.c single thread pinned to core %d, 1 warm-up + %d passes "
+                     "(min %.2f s, median %.2f s)" % (first, first + sample - 1, size, size, cores[0], reps, tmin, tmed),
+           "value_median": px / tmed, "lines_per_s": nl / tmin,
+           # the port skips the reference's two full-image scans per region; the unmodified reference was measured in the survey
+           # container (BASELINE.md section 2, other host): 3.1 Mpix/s / 175 lines/s on the 2048^2 tile, i.e. the port is ~25-40x faster
+           "true_reference_Mpix_per_s": REF_TILE2048["Mpix_per_s"], "true_reference_lines_per_s": REF_TILE2048["lines_per_s"],
+           "true_reference_source": "BASELINE.md section 2 (survey container; the reference needs OpenCV/Eigen headers and cannot be built here)"}
+    m1 = load_maps()["map1"]                                        # the port on mapValue_map1, same core (min of 30 calls)
+    t1 = []
+    for _ in range(31):
+        m = m1.copy()
         t0 = time.perf_counter()
-        r = oracle.lsd(img, want_lineim=True)
-        t_used += time.perf_counter() - t0
-        px += size * size
-        nl += len(r["lines"])
-        k += 1
-    return {"value": px / 1e6 / t_used, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "first %d images of the same %dx%d batch, oracle/lsd_oracle.c single thread, %.1f s" % (k, size, size, t_used),
-            "lines_per_s": nl / t_used}
+        r = oracle.lsd(m, want_lineim=True)
+        t1.append(time.perf_counter() - t0)
+    out["map1"] = {"ms": min(t1[1:]) * 1e3, "lines_per_s": len(r["lines"]) / min(t1[1:]), "kind": "port"}
+    try:                                                            # N-core figure: N independent pinned instances over disjoint images
+        import multiprocessing as mp
+        per = max(4, sample // 3)
+        with mp.get_context("spawn").Pool(len(cores)) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_worker, [(c, first + sample + j * per, per, size, 1) for j, c in enumerate(cores)])
+            wall = time.perf_counter() - t0
+        slowest = max(r[0][0] for r in res)                         # timed pass of the slowest instance (start-up excluded)
+        out["all_cores"] = {"cores": len(cores), "value": len(cores) * per * size * size / 1e6 / slowest, "unit": "Mpix/s",
+                            "lines_per_s": sum(r[1] for r in res) / slowest,
+                            "sample": "%d instances x %d images, each pinned to its core; slowest instance %.2f s (wall incl. start-up %.1f s)" % (
+                                len(cores), per, slowest, wall)}
+    except Exception as e:                                          # (a sandbox without process spawning: the 1-core figure stands)
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -84,10 +137,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, single-image latency, copy ceiling): what the profiling passes use")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, map1 targets, single-image latency, copy ceiling): what the profiling passes use")
     ap.add_argument("--no-lineim", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
     a = ap.parse_args()
@@ -113,9 +167,13 @@ def main():
     ctx = lsd.Context(local)
     maps = load_maps()
 
-    n, size = a.batch, a.size
-    n_total = n * world
-    first = rank * n                                       # weak scaling: every GPU gets its own 512 images
+    size = a.size
+    if a.scaling == "weak":
+        n, n_total, first = a.batch, a.batch * world, rank * a.batch      # every GPU gets its own images
+    else:
+        n_total = a.batch                                                  # the same batch, contiguous shards
+        lo, hi = ldist.shard_range(n_total, world, rank)
+        n, first = hi - lo, lo
     host = make_batch(maps, n, size, first)
     d_maps = torch.from_numpy(host).to(dev)
     del host
@@ -126,14 +184,12 @@ def main():
     ctx.reserve(n, size, size)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
+    cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)
 
     def step(collect):
         ctx.enqueue_device(d_maps.data_ptr(), n, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(),
                            d_line_ims=None if d_ims is None else d_ims.data_ptr(), stream=stream)
-        if use_dist:
-            res = ldist.gather_line_lists(d_lines, d_counts, n_total, dst=0)
-        else:
-            res = None
+        res = ldist.gather_line_lists(d_lines, d_counts, n_total, dst=0, cap_rows=cap_rows, dense=False) if use_dist else None
         if collect:                                        # HIP events recorded on the launch stream by the library
             for k, v in ctx.timings().items():
                 kt[k] += v
@@ -164,73 +220,129 @@ def main():
     overflow = int((d_counts > a.max_lines).sum().item())
 
     if rank == 0:
-        if use_dist:
-            offsets, lines = res
-            assert int(offsets[-1]) == int(total_lines) and lines.shape[0] == int(total_lines)
-        ms_per_step = dt / a.steps * 1e3
+        if use_dist:                                       # the gathered result of the last step: every line arrived, nothing overflowed
+            cnts, slabs, over = res
+            assert int(cnts.sum().item()) == int(total_lines) and not bool(over.any().item()), "gather_line_lists lost lines"
+        step_s = dt / a.steps
         mpix = n_total * size * size / 1e6
-        value = mpix / (dt / a.steps)
         grad_ms = kt["gradient"] / a.steps
         grad_bytes = GRAD_BYTES_PER_PX * w * h * n
         achieved = grad_bytes / (grad_ms * 1e-3) / 1e9 if grad_ms > 0 else 0.0
-        traffic, traffic_all = None, {}
+        traffic, traffic_all, traffic_src = None, {}, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and n == 512 and size == 2048:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("k_gradient_bytes_per_launch")
                 traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items()}
+                traffic_src = "profiles/traffic_latest.json (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run" % tj.get("build", "build not recorded")
             except Exception:
                 traffic = None
+        # per-image cycles of the region stage (s_memtime, read after the timed region): the batch time is its heaviest images
+        cyc = np.array([ctx.fetch(i, lsd.DBG_STATS, (w, h))["cycles_total"] for i in range(n)], np.float64)
+        nb_mean = float(np.mean([ctx.fetch(i, lsd.DBG_NB, (w, h)) for i in range(0, n, max(1, n // 32))]))
+        # SURVEY 8d algorithmic bytes of the whole path per image: K1 W*H + 8wh, K2 25wh, K3 8wh + 12 nb, K5 W*H (K4: latency-bound, none)
+        alg_img = 2.0 * size * size + (8 + 25 + 8) * w * h + 12.0 * nb_mean
+        reg_ms = kt["region"] / a.steps
         out = {
-            "metric": "Mpixels/sec LSD (grad+grow+NFA)", "value": value, "unit": "Mpix/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d x %dx%d u8 occupancy maps per GPU tiled/rolled/flipped from 4 aisle-class fixtures "
-                                   "(SURVEY 8d C4), full pipeline incl. lineIm, params 0.3/0.6/22.5/0.7/1024" % (n, size, size),
-                       "images_per_gpu": n, "image": [size, size], "scaled": [w, h],
+            "metric": "Mpixels/sec LSD (grad+grow+NFA)", "value": mpix / step_s, "unit": "Mpix/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d x %dx%d u8 occupancy maps %s tiled/rolled/flipped from 4 aisle-class fixtures "
+                                   "(SURVEY 8d C4), full pipeline incl. lineIm, params 0.3/0.6/22.5/0.7/1024" % (
+                                       a.batch, size, size, "per GPU" if a.scaling == "weak" else "in total, split over the GPUs"),
+                       "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU"},
-            "lines_per_s": total_lines / (dt / a.steps), "lines_per_step": total_lines, "line_overflow_images": overflow,
+            "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
             "kernel_ms": {k: v / a.steps for k, v in kt.items()},
             # informational: every kernel's HBM traffic (PMC, profiles/traffic_latest.json) over its live launch time
             "kernel_hbm_GBs": {k: traffic_all["k_" + k] / (kt[k] / a.steps * 1e-3) / 1e9
-                               for k in ("gauss", "gradient", "sort", "region", "lines")
-                               if n == 512 and size == 2048 and ("k_" + k) in traffic_all and kt[k] > 0},
+                               for k in ("gauss", "gradient", "sort", "region", "lines") if ("k_" + k) in traffic_all and kt[k] > 0},
+            # the kernel north_star prices: the gradient pass, algorithmic bytes over its HIP-event launch time of THIS run
             "roofline": {"kernel": "k_gradient", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms,
-                         "note": "north_star prices the gradient pass; k_region takes 97% of the step but is a serial latency chain "
-                                 "(about 2% of HBM peak, no MFMA work): DESIGN.md section 4, kernel_hbm_GBs below"},
+                         "note": "k_gradient is the pass north_star prices, not the dominant kernel: see dominant_kernel / roofline_pipeline"},
+            # ... and the whole truth next to it: the step is the region stage, a serial-latency / instruction-issue bound kernel
+            "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (step_s * 1e3),
+                                "Mpix_per_s": n * size * size / 1e6 / (reg_ms * 1e-3), "lines_per_s": float(d_counts.sum().item()) / (reg_ms * 1e-3),
+                                "bound": "serial dependence per image (no HBM / MFMA roofline applies): DESIGN.md section 4",
+                                "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean())}},
+            "roofline_pipeline": {"bound": "hbm", "algorithmic_bytes_per_step": alg_img * n, "achieved": alg_img * n_total / step_s / 1e9,
+                                  "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg_img * n_total / step_s / 1e9 / (HBM_PEAK_GBS * world),
+                                  "note": "SURVEY 8d algorithmic bytes of the whole path (K1+K2+K3+K5; %.1f MB per image) over the step time" % (alg_img / 1e6)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            # extras outside the timed region: single-image latency, and the device-copy ceiling of this box
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            lat = []
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                ctx.enqueue_device(d_maps.data_ptr(), 1, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(),
-                                   d_line_ims=None if d_ims is None else d_ims.data_ptr(), stream=stream)
-                torch.cuda.synchronize()
-                lat.append((time.perf_counter() - t1) * 1e3)
-            out["single_image_latency_ms"] = min(lat)
-            src_t = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-            dst_t = torch.empty_like(src_t)
-            dst_t.copy_(src_t)
-            ev0.record()
-            for _ in range(5):
-                dst_t.copy_(src_t)
-            ev1.record()
-            torch.cuda.synchronize()
-            out["roofline"]["measured_copy_GBs"] = 5 * 2 * (1 << 30) / (ev0.elapsed_time(ev1) * 1e-3) / 1e9   # read + write
-            del src_t, dst_t
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(maps, size, first)
+            extras(out, a, ctx, lsd, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size)
+            out["cpu_baseline"] = cpu_baseline(size, first)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def extras(out, a, ctx, lsd, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size):
+    """Outside the timed region: what north_star asks for on mapValue_map1, single-image latency, device copy ceiling."""
+    import torch
+    ims = None if d_ims is None else d_ims.data_ptr()
+    lat = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ctx.enqueue_device(d_maps.data_ptr(), 1, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(), d_line_ims=ims, stream=stream)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    out["single_image_latency_ms"] = min(lat)
+    # -- mapValue_map1 (608 x 480, 7 lines): (a) the reference's usage, ONE host-ABI call createMapCache + myLineSegmentDetector
+    #    (LSD/main_on_windows.cpp:67-70), wall time incl. PCIe; (b) throughput on 512 replicas resident in HBM (SURVEY 8d)
+    m1 = maps["map1"]
+    rows, cols = m1.shape
+    both, lsd_only = [], []
+    for _ in range(22):
+        m = m1.copy()
+        t1 = time.perf_counter()
+        ctx.map_cache(m, 0.05)
+        t2 = time.perf_counter()
+        lines, _ = ctx.run(m)
+        t3 = time.perf_counter()
+        both.append((t3 - t1) * 1e3); lsd_only.append((t3 - t2) * 1e3)
+    assert len(lines) == 7
+    reps = 512
+    d1 = torch.from_numpy(np.broadcast_to(m1, (reps, rows, cols)).copy()).to(dev)
+    l1 = torch.zeros((reps, 64, 10), dtype=torch.int64, device=dev)
+    c1 = torch.zeros(reps, dtype=torch.int32, device=dev)
+    i1 = torch.zeros((reps, rows, cols), dtype=torch.uint8, device=dev)
+    tt = []
+    for it in range(6):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ctx.enqueue_device(d1.data_ptr(), reps, cols, rows, l1.data_ptr(), 64, c1.data_ptr(), d_line_ims=i1.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        if it:
+            tt.append(time.perf_counter() - t1)
+    assert int(c1.min().item()) == int(c1.max().item()) == 7
+    tb = min(tt)
+    out["map1"] = {
+        "single_call_ms": statistics.median(both[2:]), "single_call_lsd_only_ms": statistics.median(lsd_only[2:]),
+        "single_call_note": "host ABI (lsd_map_cache + lsd_run), wall clock incl. staging and PCIe, median of 20",
+        "batch512_ms": tb * 1e3, "batch512_lines_per_s": reps * 7 / tb, "batch512_Mpix_per_s": reps * rows * cols / 1e6 / tb,
+        "reference_single_thread": REF_MAP1, "reference_source": "BASELINE.md section 2 (unmodified reference, survey container)",
+        "lines_per_s_vs_reference": reps * 7 / tb / REF_MAP1["lines_per_s"],
+        "single_call_vs_reference": REF_MAP1["ms"] / statistics.median(lsd_only[2:]),
+        "kernel_ms_batch512": ctx.timings()}
+    del d1, l1, c1, i1
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    src_t = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst_t = torch.empty_like(src_t)
+    dst_t.copy_(src_t)
+    ev0.record()
+    for _ in range(5):
+        dst_t.copy_(src_t)
+    ev1.record()
+    torch.cuda.synchronize()
+    out["roofline"]["measured_copy_GBs"] = 5 * 2 * (1 << 30) / (ev0.elapsed_time(ev1) * 1e-3) / 1e9   # read + write
+    del src_t, dst_t
 
 
 if __name__ == "__main__":

@@ -72,7 +72,8 @@ void lsd_free(void *p);
  *              caller's image is rewritten (1 -> 255, 255 -> 0 for y >= 1, x >= 1; myLSD.cpp:135-142).
  *   line_im    rows x cols uint8 (pitch line_im_stride), receives structLSD.lineIm (0/255), or NULL.
  *   lines_out  receives a malloc'ed array of *n_lines lsd_line (structLSD.linesInfo; free with lsd_free).
- * Blocking; uses the context's own stream. */
+ * Blocking; uses the context's own streams.  Host buffers travel through pinned double buffers; the rewritten map comes
+ * back while the rest of the pipeline still runs; the lines arrive compacted in one copy. */
 int lsd_run(lsd_ctx *ctx, uint8_t *map, int cols, int rows, size_t stride, const lsd_params *p,
             uint8_t *line_im, size_t line_im_stride, lsd_line **lines_out, int *n_lines);
 
@@ -81,6 +82,10 @@ int lsd_run(lsd_ctx *ctx, uint8_t *map, int cols, int rows, size_t stride, const
  * concatenated lines (malloc'ed).  maps are rewritten like lsd_run does.  line_ims may be NULL. */
 int lsd_run_batch(lsd_ctx *ctx, uint8_t *maps, int n, int cols, int rows, const lsd_params *p,
                   uint8_t *line_ims, lsd_line **lines_out, int *offsets_out);
+
+/* Line capacity per image of the host entry points above (default 8192; the device entry point takes it as an argument).
+ * An image with more lines returns its first max_lines and the call reports LSD_ERR_CAPACITY (lines_out is still valid). */
+int lsd_set_host_max_lines(lsd_ctx *ctx, int max_lines);
 
 /* --- the hot path, device-resident batch ------------------------------------------------ */
 /* Same computation on buffers that already live in HBM (e.g. torch tensors' data_ptr()).

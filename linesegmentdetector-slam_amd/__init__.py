@@ -99,6 +99,7 @@ def load_library(path=None):
     L.lsd_set_stop_after.restype = i; L.lsd_set_stop_after.argtypes = [vp, i]
     L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
     L.lsd_set_region_waves.restype = i; L.lsd_set_region_waves.argtypes = [vp, i]
+    L.lsd_set_host_max_lines.restype = i; L.lsd_set_host_max_lines.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
     L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
     L.lsd_map_cache.restype = i; L.lsd_map_cache.argtypes = [vp, vp, i, i, sz, dbl, dbl, vp]
@@ -120,7 +121,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device"]
@@ -172,13 +173,14 @@ class Context:
         p = params or make_params()
         line_im = np.zeros((rows, cols), np.uint8) if want_lineim else None
         lines_p, n = C.c_void_p(), C.c_int()
-        self._chk(self.L.lsd_run(self.h, map_u8.ctypes.data, cols, rows, map_u8.strides[0], C.byref(p),
-                                 line_im.ctypes.data if want_lineim else None, cols, C.byref(lines_p), C.byref(n)))
-        lines = np.zeros(n.value, LINE_DTYPE)
-        if n.value:
-            C.memmove(lines.ctypes.data, lines_p, 80 * n.value)
+        st = self.L.lsd_run(self.h, map_u8.ctypes.data, cols, rows, map_u8.strides[0], C.byref(p),
+                            line_im.ctypes.data if want_lineim else None, cols, C.byref(lines_p), C.byref(n))
+        lines = np.zeros(n.value if lines_p else 0, LINE_DTYPE)
+        if len(lines):
+            C.memmove(lines.ctypes.data, lines_p, 80 * len(lines))
             lines["_pad"] = 0
-        self.L.lsd_free(lines_p)
+        self.L.lsd_free(lines_p)                                   # (before any raise: the C side has handed the buffer over)
+        self._chk(st)
         return lines, line_im
 
     def run_batch(self, maps_u8, params=None, want_lineim=True):
@@ -189,14 +191,15 @@ class Context:
         line_ims = np.zeros((n, rows, cols), np.uint8) if want_lineim else None
         lines_p = C.c_void_p()
         offs = (C.c_int * (n + 1))()
-        self._chk(self.L.lsd_run_batch(self.h, maps_u8.ctypes.data, n, cols, rows, C.byref(p),
-                                       line_ims.ctypes.data if want_lineim else None, C.byref(lines_p), offs))
+        st = self.L.lsd_run_batch(self.h, maps_u8.ctypes.data, n, cols, rows, C.byref(p),
+                                  line_ims.ctypes.data if want_lineim else None, C.byref(lines_p), offs)
         offsets = np.frombuffer(offs, np.int32).copy()
-        lines = np.zeros(int(offsets[-1]), LINE_DTYPE)
+        lines = np.zeros(int(offsets[-1]) if lines_p else 0, LINE_DTYPE)
         if len(lines):
             C.memmove(lines.ctypes.data, lines_p, 80 * len(lines))
             lines["_pad"] = 0
-        self.L.lsd_free(lines_p)
+        self.L.lsd_free(lines_p)                                   # (before any raise: the C side has handed the buffer over)
+        self._chk(st)
         return lines, offsets, line_ims
 
     # -- device-resident batch --------------------------------------------------------------------
@@ -264,6 +267,10 @@ class Context:
 
     def set_trace(self, on):
         self._chk(self.L.lsd_set_trace(self.h, 1 if on else 0))
+
+    def set_host_max_lines(self, max_lines):
+        """Line capacity per image of run / run_batch (default 8192); more lines -> LsdError(LSD_ERR_CAPACITY)."""
+        self._chk(self.L.lsd_set_host_max_lines(self.h, max_lines))
 
     def set_region_waves(self, waves):
         """0: automatic, 4 / 8: force the region-stage variant (results are identical)."""

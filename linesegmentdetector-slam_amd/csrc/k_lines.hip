@@ -60,8 +60,35 @@ __global__ __launch_bounds__(256) void k_lines(const double* __restrict__ recs_s
             L.len = sqrt(ey * ey + ex * ex);                                       // :366
             L.orient = orient;
             out[i] = L;
+            reinterpret_cast<uint32_t*>(&out[i])[19] = 0u;      // the tail padding of structLinesInfo: defined bytes (records are compared and moved as words)
         }
     }
+}
+
+// Host entry points: the per-image line arrays (max_lines apart) compacted into one flat array + prefix offsets, so that
+// the host fetches exactly the lines there are in one copy.  offsets[n + 1]; counts beyond max_lines are clamped.
+__global__ __launch_bounds__(256) void k_compact_lines(const lsd_line* __restrict__ lines, const int32_t* __restrict__ counts,
+                                                       int max_lines, int n, lsd_line* __restrict__ flat, int32_t* __restrict__ offsets) {
+    __shared__ int s_off;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < n; i++) { offsets[i] = run; run += min(counts[i], max_lines); }
+        offsets[n] = run;
+    }
+    __syncthreads();
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(lines);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(flat);
+    for (int i = 0; i < n; i++) {
+        if (threadIdx.x == 0) s_off = offsets[i];
+        __syncthreads();
+        const int k = min(counts[i], max_lines) * 10, o = s_off * 10;
+        for (int j = threadIdx.x; j < k; j += 256) dst[o + j] = src[(size_t)i * max_lines * 10 + j];
+        __syncthreads();
+    }
+}
+
+void launch_compact_lines(const lsd_line* lines, const int32_t* counts, int max_lines, int n, lsd_line* flat, int32_t* offsets, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_lines, dim3(1), dim3(256), 0, s, lines, counts, max_lines, n, flat, offsets);
 }
 
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s) {

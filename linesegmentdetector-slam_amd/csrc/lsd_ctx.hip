@@ -46,10 +46,13 @@ struct lsd_ctx {
     int32_t *nb = nullptr, *nseed = nullptr;
     long long* stats = nullptr;
     void* seeds = nullptr;
-    // host-API staging
+    // host-API staging (device side), and the pinned host buffers every host <-> device copy goes through
     uint8_t *h_in = nullptr, *h_lineim = nullptr;
-    lsd_line* h_lines = nullptr;
-    int32_t* h_counts = nullptr;
+    lsd_line *h_lines = nullptr, *h_flat = nullptr;
+    int32_t *h_counts = nullptr, *h_offs = nullptr;
+    uint8_t* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;  // second stream: the remapped maps travel back while the rest of the pipeline runs
     size_t hcap_n = 0, hcap_wh = 0;
     int hcap_max_lines = 0;
     bool hcap_lineim = false;
@@ -84,6 +87,8 @@ struct lsd_ctx {
     hipEvent_t ev_done = nullptr;      // end of the last enqueue: a later enqueue on ANOTHER stream waits for it (shared workspace)
     bool done_valid = false;
 };
+
+constexpr size_t kPinBytes = 32u << 20;   // two pinned staging buffers of this size per context
 
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
@@ -305,6 +310,10 @@ int lsd_create(lsd_ctx** out, int device) {
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return LSD_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LSD_ERR_HIP; }
+    for (int k = 0; k < 2; k++)
+        if (hipHostMalloc((void**)&c->pin[k], kPinBytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_NOMEM; }
     c->last_stream = c->stream;
     *out = c;
     return LSD_OK;
@@ -320,6 +329,10 @@ void lsd_destroy(lsd_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->h_flat) (void)hipFree(c->h_flat);
+    if (c->h_offs) (void)hipFree(c->h_offs);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -433,6 +446,42 @@ int lsd_last_timings(lsd_ctx* c, float ms[6]) {
     return LSD_OK;
 }
 
+// Host -> device through the two pinned buffers: the memcpy into one overlaps the DMA out of the other.
+static int h2d_staged(lsd_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    size_t off = 0;
+    for (int k = 0; off < bytes; k++) {
+        const int b = k & 1;
+        const size_t len = bytes - off < kPinBytes ? bytes - off : kPinBytes;
+        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
+        memcpy(c->pin[b], (const uint8_t*)src + off, len);
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + off, c->pin[b], len, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], s));
+        off += len;
+    }
+    return LSD_OK;
+}
+// Device -> host the same way (returns when the bytes are in dst).
+static int d2h_staged(lsd_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    size_t off = 0, prev_off = 0, prev_len = 0;
+    for (int k = 0; off < bytes; k++) {
+        const int b = k & 1;
+        const size_t len = bytes - off < kPinBytes ? bytes - off : kPinBytes;
+        HIPCHK(c, hipMemcpyAsync(c->pin[b], (const uint8_t*)src + off, len, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], s));
+        if (prev_len) {
+            HIPCHK(c, hipEventSynchronize(c->pin_ev[b ^ 1]));
+            memcpy((uint8_t*)dst + prev_off, c->pin[b ^ 1], prev_len);
+        }
+        prev_off = off; prev_len = len;
+        off += len;
+        if (off >= bytes) {
+            HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
+            memcpy((uint8_t*)dst + prev_off, c->pin[b], prev_len);
+        }
+    }
+    return LSD_OK;
+}
+
 static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, bool lineim) {
     if (n > c->hcap_n || wh > c->hcap_wh || max_lines > c->hcap_max_lines || (lineim && !c->hcap_lineim)) {
         const size_t nn = n > c->hcap_n ? n : c->hcap_n, ww = wh > c->hcap_wh ? wh : c->hcap_wh;
@@ -442,8 +491,8 @@ static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, b
         HIPCHK(c, hipDeviceSynchronize());
         HIPCHK(c, re_alloc(&c->h_in, nn * ww));
         HIPCHK(c, re_alloc(&c->h_lineim, li ? nn * ww : 0));
-        HIPCHK(c, re_alloc(&c->h_lines, nn * (size_t)ml));
-        HIPCHK(c, re_alloc(&c->h_counts, nn));
+        HIPCHK(c, re_alloc(&c->h_lines, nn * (size_t)ml)); HIPCHK(c, re_alloc(&c->h_flat, nn * (size_t)ml));
+        HIPCHK(c, re_alloc(&c->h_counts, nn)); HIPCHK(c, re_alloc(&c->h_offs, nn + 1));
         c->hcap_n = nn; c->hcap_wh = ww; c->hcap_max_lines = ml; c->hcap_lineim = li;
     }
     return LSD_OK;
@@ -462,33 +511,39 @@ int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const ls
     st = ensure_host_staging(c, (size_t)n, wh, ml, line_ims != nullptr);
     if (st != LSD_OK) return st;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->h_in, maps, (size_t)n * wh, hipMemcpyHostToDevice, s));
+    st = h2d_staged(c, c->h_in, maps, (size_t)n * wh, s);
+    if (st != LSD_OK) return st;
     st = lsd_enqueue_batch_device(c, c->h_in, n, cols, rows, p, LSD_FLAG_WRITEBACK_MAP, line_ims ? c->h_lineim : nullptr,
                                   c->h_lines, ml, c->h_counts, s);
     if (st != LSD_OK) return st;
-    std::vector<int32_t> counts(n);
-    HIPCHK(c, hipMemcpyAsync(counts.data(), c->h_counts, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(maps, c->h_in, (size_t)n * wh, hipMemcpyDeviceToHost, s));      // observable in-place remap
-    if (line_ims) HIPCHK(c, hipMemcpyAsync(line_ims, c->h_lineim, (size_t)n * wh, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    int total = 0, status = LSD_OK;
-    offsets_out[0] = 0;
-    for (int i = 0; i < n; i++) {
-        int k = counts[i];
-        if (k > ml) { k = ml; status = LSD_ERR_CAPACITY; }
-        total += k;
-        offsets_out[i + 1] = total;
-    }
+    launch_compact_lines(c->h_lines, c->h_counts, ml, n, c->h_flat, c->h_offs, s);
+    // the observable in-place remap is final after K1 (event 1 of the enqueue): it travels back on the second stream while
+    // the gradient / sort / region / line kernels run
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev[1], 0));
+    st = d2h_staged(c, maps, c->h_in, (size_t)n * wh, c->copy_stream);
+    if (st != LSD_OK) return st;
+    st = d2h_staged(c, offsets_out, c->h_offs, sizeof(int32_t) * (size_t)(n + 1), s);          // (waits for the pipeline)
+    if (st != LSD_OK) return st;
+    const int total = offsets_out[n];
     lsd_line* out = (lsd_line*)calloc(total > 0 ? total : 1, sizeof(lsd_line));
     if (!out) return LSD_ERR_NOMEM;
-    for (int i = 0; i < n; i++) {
-        const int k = offsets_out[i + 1] - offsets_out[i];
-        if (k > 0)
-            HIPCHK(c, hipMemcpy(out + offsets_out[i], c->h_lines + (size_t)i * ml, sizeof(lsd_line) * k,
-                                hipMemcpyDeviceToHost));
-    }
+    st = total > 0 ? d2h_staged(c, out, c->h_flat, sizeof(lsd_line) * (size_t)total, s) : LSD_OK;
+    if (st == LSD_OK && line_ims) st = d2h_staged(c, line_ims, c->h_lineim, (size_t)n * wh, s);
+    if (st != LSD_OK) { free(out); return st; }
+    // more lines than host_max_lines in some image: the first host_max_lines of it are returned, and the status says so
+    std::vector<int32_t> counts(n);
+    st = d2h_staged(c, counts.data(), c->h_counts, sizeof(int32_t) * (size_t)n, s);
+    if (st != LSD_OK) { free(out); return st; }
+    int status = LSD_OK;
+    for (int i = 0; i < n; i++) if (counts[i] > ml) status = LSD_ERR_CAPACITY;
     *lines_out = out;
     return status;
+}
+
+int lsd_set_host_max_lines(lsd_ctx* c, int max_lines) {
+    if (!c || max_lines < 1 || max_lines > (1 << 20)) return LSD_ERR_INVALID;
+    c->host_max_lines = max_lines;
+    return LSD_OK;
 }
 
 int lsd_run(lsd_ctx* c, uint8_t* map, int cols, int rows, size_t stride, const lsd_params* p, uint8_t* line_im,
@@ -605,12 +660,12 @@ int lsd_map_cache(lsd_ctx* c, const uint8_t* map, int cols, int rows, size_t str
         HIPCHK(c, re_alloc(&c->mc_in, wh)); HIPCHK(c, re_alloc(&c->mc_out, wh));
         c->mc_hcap = wh;
     }
-    HIPCHK(c, hipMemcpy2DAsync(c->mc_in, cols, map, stride, cols, rows, hipMemcpyHostToDevice, c->stream));
-    const int st = lsd_enqueue_map_cache_device(c, c->mc_in, 1, cols, rows, res, z_occ_max_dis, c->mc_out, c->stream);
+    int st;
+    if (stride == (size_t)cols) { st = h2d_staged(c, c->mc_in, map, wh, c->stream); if (st != LSD_OK) return st; }
+    else HIPCHK(c, hipMemcpy2DAsync(c->mc_in, cols, map, stride, cols, rows, hipMemcpyHostToDevice, c->stream));
+    st = lsd_enqueue_map_cache_device(c, c->mc_in, 1, cols, rows, res, z_occ_max_dis, c->mc_out, c->stream);
     if (st != LSD_OK) return st;
-    HIPCHK(c, hipMemcpyAsync(out, c->mc_out, wh * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return LSD_OK;
+    return d2h_staged(c, out, c->mc_out, wh * sizeof(double), c->stream);
 }
 
 int lsd_enqueue_occupancy_to_map_device(lsd_ctx* c, const int8_t* d_grid, size_t n_cells, uint8_t* d_map, void* stream) {

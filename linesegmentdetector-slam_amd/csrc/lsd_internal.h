@@ -105,6 +105,7 @@ void launch_mapcache_spread(const uint8_t* maps, double* out, unsigned long long
 void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_compact_lines(const lsd_line* lines, const int32_t* counts, int max_lines, int n, lsd_line* flat, int32_t* offsets, hipStream_t s);
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 
 // x86-64 cvttsd2si semantics of the reference's (int) casts: NaN, +-inf and

@@ -11,6 +11,7 @@ UsedMap indexing"):
   * line endpoints x1,y1,x2,y2 and len: 1e-6 px absolute; dx,dy: 1e-9; k,b: 1e-6 relative
     (transcendentals on the rectangle path differ by ulps between OCML and glibc).
 """
+import importlib
 import os
 import subprocess
 import sys
@@ -371,6 +372,27 @@ def test_whole_bench_batch_matches_oracle(maps, lsdmod, ctx, oracle):
     torch.cuda.empty_cache()
 
 
+def test_bench_strong_scaling_split(maps, lsdmod, ctx):
+    """bench.py --scaling strong (BASELINE configs[4]: the SAME batch split over the ranks by dist.shard_range) with world size 1:
+    the JSON line carries the whole batch's answer."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--scaling", "strong", "--batch", "6", "--size", "1024",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["scaling"] == "strong" and j["config"]["images_total"] == 6 and j["n_gpus"] == 1
+    lines, offs, _ = ctx.run_batch(bench.make_batch(maps, 6, 1024))
+    assert j["lines_per_step"] == len(lines) == offs[-1]
+    assert j["roofline"]["kernel"] == "k_gradient" and j["dominant_kernel"]["name"] == "k_region"
+    assert j["dominant_kernel"]["cycles_per_image"]["max_over_mean"] >= 1.0
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    assert [ldist.shard_range(6, 4, r) for r in range(4)] == [(0, 2), (2, 3), (3, 5), (5, 6)]    # what each of 4 ranks would take
+
+
 def test_cpp_adapter_runs(maps, tmp_path):
     """The C++ host side (include/myLSD.h) end to end: same line count as the recorded reference answer."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -478,6 +500,24 @@ def test_error_codes(maps, lsdmod, ctx):
     assert L.lsd_strerror(lsdmod.LSD_ERR_UNSUPPORTED) and L.lsd_last_error(h) is not None
     got_lines, _ = ctx.run(img)                                                   # and the context is still usable
     assert len(got_lines) == 7
+
+
+def test_scaled_size_limit_and_host_line_capacity(maps, lsdmod, ctx):
+    """The region stage keeps scaled coordinates and boxes in 16-bit fields: a scaled width beyond 32766 is refused, not
+    mis-computed (sca >= 1 on a wide map).  The host entry points report an image with more lines than their capacity."""
+    wide = np.zeros((4, 40000), np.uint8)
+    with pytest.raises(lsdmod.LsdError) as e:
+        ctx.run(wide, lsdmod.make_params(sca=1.0))
+    assert e.value.status == lsdmod.LSD_ERR_UNSUPPORTED
+    ctx.set_host_max_lines(8)
+    try:
+        with pytest.raises(lsdmod.LsdError) as e:
+            ctx.run(maps["aisle1"].copy())                                        # 75 lines
+        assert e.value.status == lsdmod.LSD_ERR_CAPACITY
+    finally:
+        ctx.set_host_max_lines(8192)
+    lines, _ = ctx.run(maps["aisle1"].copy())
+    assert len(lines) == 75
 
 
 # ---- wire format (SURVEY 8f next #3): OccupancyGrid cells -> map values on the device (byte-exact) ------------
