@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer probe: per-image cost of the region stage (8 waves, whole bench batch) next to cheap predictors -> gpurun_out/costs.npz"""
+"""Developer probe: per-image cycles of the region stage with 4 and with 8 waves (whole bench batch) next to nb -> gpurun_out/costs.npz"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +13,12 @@ d = torch.from_numpy(bench.make_batch(maps, n, size)).cuda()
 lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 wh = lsd.scaled_size(size, size)
-ctx.set_region_waves(8)
-for rep in range(2):
-    ctx.enqueue_device(d.data_ptr(), n, size, size, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
-st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
-nb = np.array([ctx.fetch(i, lsd.DBG_NB, wh) for i in range(n)])
-keys = ("cycles_total", "seeds", "grown_px", "grow_calls", "nfa_calls")
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-np.savez(os.path.join(ROOT, "gpurun_out", "costs.npz"), nb=nb, lines=counts.cpu().numpy(), **{k: np.array([x[k] for x in st]) for k in keys})
-print("ok", ctx.timings())
+res = {}
+for waves in (4, 8):
+    ctx.set_region_waves(waves)
+    for rep in range(2):
+        ctx.enqueue_device(d.data_ptr(), n, size, size, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
+    res["t%d" % waves] = np.array([ctx.fetch(i, lsd.DBG_STATS, wh)["cycles_total"] for i in range(n)])
+    print(waves, ctx.timings()["region"])
+res["nb"] = np.array([ctx.fetch(i, lsd.DBG_NB, wh) for i in range(n)])
+np.savez(os.path.join(ROOT, "gpurun_out", "costs.npz"), **res)

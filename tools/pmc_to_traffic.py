@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Derives profiles/traffic_latest.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 
-usage: pmc_to_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json]
+usage: pmc_to_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json [build tag]]
 Counters are KB per dispatch.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the factor 2 on FETCH_SIZE is
 the gfx950 correction of MI355X_MICROARCH.md, confirmed for this code's 8-B-per-lane loads with tools/pmc_calib.py."""
 import csv, glob, json, os, sys
@@ -25,13 +25,14 @@ def per_kernel(d, counter):
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
+    build = sys.argv[4] if len(sys.argv) > 4 else "build not recorded"
     f, nf = per_kernel(fd, "FETCH_SIZE")
     w, nw = per_kernel(wd, "WRITE_SIZE")
     res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
            "--no-cpu-baseline` (512 x 2048^2); counters are KB per dispatch, averaged over the launches of each kernel; "
            "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (confirmed for 8-B-per-lane loads with "
            "tools/pmc_calib.py: profiles/r01b_pmc_calib_*.csv)",
-           "kernels": {}}
+           "build": build, "kernels": {}}
     for k in KERNELS:
         if k in f and k in w:
             res["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k], "launches": [nf[k], nw[k]],
