@@ -160,9 +160,9 @@ enum { LSD_STAGE_ALL = 0, LSD_STAGE_GAUSS = 1, LSD_STAGE_GRAD = 2, LSD_STAGE_SOR
 int lsd_set_stop_after(lsd_ctx *ctx, int stage);
 /* Enables the per-seed trace buffer (LSD_DBG_SEEDS); costs one record store per grown seed. */
 int lsd_set_trace(lsd_ctx *ctx, int on);
-/* Region stage variant: 4 wavefronts per image (two images per CU: batches that fill the device) or 8 (one image per CU,
- * ~1.5x lower latency per image).  0 (default) picks 8 while the batch has at most one image per CU.  Results do not
- * depend on the choice. */
+/* Region stage variant: 4 wavefronts per image (two images per CU) or 8 (one image per CU, ~1.4x lower latency per
+ * image, images taken heaviest first).  0 (default) picks 8 while the batch has at most four images per CU (the step is
+ * bounded by its heaviest image until then) and 4 beyond.  Results do not depend on the choice. */
 int lsd_set_region_waves(lsd_ctx *ctx, int waves);
 
 /* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
@@ -175,10 +175,13 @@ int lsd_set_region_waves(lsd_ctx *ctx, int waves);
  *   RECS           count*12 doubles accepted structRec before rescale (x1 y1 x2 y2 wid cX cY deg dx dy p prec)
  *   SEEDS          n_seed records {int order_idx, x, y, num, outcome, final_num; double logNFA}
  *   NSEED          1 int32
- *   STATS          32 int64         grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, list_spills,
- *                                   cycles_total, cycles_grow, cycles_rect, cycles_nfa, cycles_mark, max_region, nfa_px, seeds,
- *                                   exact_angle_evals, tile_fetches, batches, cycles_tiles, spec_redos, spec_discards, cycles_wait, (1 reserved)
- *                                   (counters are summed over the wavefronts that share an image)
+ *   STATS          32 int64         grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel, rrr_oob, cycles_rrr*,
+ *                                   cycles_total, cycles_grow*, cycles_rect*, cycles_nfa*, cycles_mark*, max_region*, nfa_px*, seeds,
+ *                                   exact_angle_evals*, tile_fetches*, batches*, cycles_tiles*, spec_redos, spec_discards, cycles_wait*,
+ *                                   resweep_batches*, slow_batches*, cycles_eval*, cycles_sums*, cycles_refine*, cycles_idle*,
+ *                                   cycles_select*, cycles_commit*, filter_skips*
+ *                                   (summed over the wavefronts that share an image; * = counted by the developer build only,
+ *                                   `make stats` -> liblsdhip_stats.so, and 0 in the product build)
  * Returns LSD_ERR_INVALID if `bytes` is smaller than the item. */
 enum { LSD_DBG_GAUSS = 1, LSD_DBG_MAG, LSD_DBG_DEG, LSD_DBG_STATE, LSD_DBG_ORDER, LSD_DBG_ORDER_VAL,
        LSD_DBG_NB, LSD_DBG_MAXGRAD, LSD_DBG_RECS, LSD_DBG_SEEDS, LSD_DBG_NSEED, LSD_DBG_STATS };
