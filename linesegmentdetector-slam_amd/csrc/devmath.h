@@ -9,12 +9,14 @@ namespace lsdhip {
 // Out of line on purpose: the double-double bodies are ~2-3 KB of code each and the region kernel has to fit the
 // instruction cache; they are called a few times per region, never per pixel of the serial chain.
 __device__ __noinline__ void sincos_g(double x, double& s, double& c) {
+    if (crm::sincos_fast(x, s, c)) return;                     // first stage (Ziv): certain roundings only
     if (!crm::sincos_cr(x, s, c)) { s = sin(x); c = cos(x); }
 }
 __device__ inline double sin_g(double x) { double s, c; sincos_g(x, s, c); return s; }
 __device__ inline double cos_g(double x) { double s, c; sincos_g(x, s, c); return c; }
 __device__ __noinline__ double atan2_g(double y, double x) {
     double r;
+    if (crm::atan2_fast(y, x, r)) return r;                    // first stage (Ziv): certain roundings only
     if (!crm::atan2_cr(y, x, r)) r = atan2(y, x);
     return r;
 }

@@ -39,14 +39,21 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
                                                  double* __restrict__ deg, double2* __restrict__ sc,
                                                  uint32_t* __restrict__ pw,
                                                  unsigned long long* __restrict__ maxbits, int w, int h, int gp,
-                                                 double gradThre) {
+                                                 double gradThre, unsigned gx, unsigned gy, unsigned strips) {
     __shared__ uint32_t l_px[CAP];           // (strip-local pixel index << 1) | growable
     __shared__ double2 l_g[CAP];             // in: (gradX, gradY) of the listed pixel; out: (angle, -)
-    const size_t img = blockIdx.z;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2), so the strips are
+    // numbered such that one XCD walks a contiguous eighth of the batch: the row above a strip and the column left of it
+    // then come out of the L2 that the neighbouring strip has just filled instead of from HBM again.
+    const unsigned per = (strips + 7u) >> 3;
+    const unsigned t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (t >= strips) return;
+    const unsigned bx = t % gx, tq = t / gx, by = tq % gy;
+    const size_t img = tq / gy;
     const size_t base = img * (size_t)w * h;
     const double* __restrict__ gim = gauss + img * (size_t)gp * h;
     const int lane = threadIdx.x;
-    const int x = blockIdx.x * GX + lane, y0 = blockIdx.y * GR;
+    const int x = (int)bx * GX + lane, y0 = (int)by * GR;
     const bool colok = x < w;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     int cnt = 0;                                               // entries in the LDS list (wave-uniform)
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
             l_g[i] = make_double2(d, 0.0);
             if (e & 1u) {                                      // sin/cos(deg) for RegionGrower (:545-546)
                 const int lt = (int)(e >> 1);
-                const size_t p = base + (size_t)(y0 + lt / GX) * w + (blockIdx.x * GX + lt % GX);
+                const size_t p = base + (size_t)(y0 + lt / GX) * w + ((int)bx * GX + lt % GX);
                 double sv, cv;
                 sincos_g(d, sv, cv);
                 sc[p] = make_double2(sv, cv);
@@ -166,9 +173,9 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
 }
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
-    dim3 grid((g.w + GX - 1) / GX, (g.h + GR - 1) / GR, n);
-    hipLaunchKernelGGL(k_gradient, grid, dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits, g.w, g.h, g.gp,
-                       g.gradThre);
+    const unsigned gx = (g.w + GX - 1) / GX, gy = (g.h + GR - 1) / GR, strips = gx * gy * (unsigned)n;
+    hipLaunchKernelGGL(k_gradient, dim3(((strips + 7u) >> 3) * 8u), dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits,
+                       g.w, g.h, g.gp, g.gradThre, gx, gy, strips);
 }
 
 }  // namespace lsdhip

@@ -16,6 +16,45 @@ int crm_atan_n(const double* v, double* out, long n) {
     for (long i = 0; i < n; i++) if (!crm::atan_cr(v[i], out[i])) { out[i] = atan(v[i]); bad++; }
     return bad;
 }
+// first stage against the full evaluation: returns the number of inputs the first stage answered; *bad counts answers that
+// differ from the full evaluation in any bit
+long crm_sincos_fast_n(const double* x, long n, long* bad) {
+    long acc = 0; *bad = 0;
+    for (long i = 0; i < n; i++) {
+        double s, c, s2, c2;
+        if (!crm::sincos_fast(x[i], s, c)) continue;
+        acc++;
+        if (!crm::sincos_cr(x[i], s2, c2)) { s2 = sin(x[i]); c2 = cos(x[i]); }
+        if (__builtin_memcmp(&s, &s2, 8) || __builtin_memcmp(&c, &c2, 8)) ++*bad;
+    }
+    return acc;
+}
+long crm_atan2_fast_n(const double* y, const double* x, long n, long* bad) {
+    long acc = 0; *bad = 0;
+    for (long i = 0; i < n; i++) {
+        double r, r2;
+        if (!crm::atan2_fast(y[i], x[i], r)) continue;
+        acc++;
+        if (!crm::atan2_cr(y[i], x[i], r2)) r2 = atan2(y[i], x[i]);
+        if (__builtin_memcmp(&r, &r2, 8)) ++*bad;
+    }
+    return acc;
+}
+// the unrounded first-stage values (hi, lo), for the error-bound test
+void crm_sincos_fast_raw_n(const double* x, double* out, long n) {      // out[6*i..]: answered, s.hi, s.lo, c.hi, c.lo, -
+    for (long i = 0; i < n; i++) {
+        double s, c; crm::dd raw[2] = {{0, 0}, {0, 0}};
+        out[6 * i] = crm::sincos_fast(x[i], s, c, raw) ? 1.0 : 0.0;
+        out[6 * i + 1] = raw[0].hi; out[6 * i + 2] = raw[0].lo; out[6 * i + 3] = raw[1].hi; out[6 * i + 4] = raw[1].lo; out[6 * i + 5] = 0;
+    }
+}
+void crm_atan2_fast_raw_n(const double* y, const double* x, double* out, long n) {   // out[3*i..]: answered, |r|.hi, |r|.lo
+    for (long i = 0; i < n; i++) {
+        double r; crm::dd raw = {0, 0};
+        out[3 * i] = crm::atan2_fast(y[i], x[i], r, &raw) ? 1.0 : 0.0;
+        out[3 * i + 1] = raw.hi; out[3 * i + 2] = raw.lo;
+    }
+}
 void libm_sincos_n(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) { s[i] = sin(x[i]); c[i] = cos(x[i]); } }
 void libm_atan2_n(const double* y, const double* x, double* out, long n) { for (long i = 0; i < n; i++) out[i] = atan2(y[i], x[i]); }
 void libm_atan_n(const double* v, double* out, long n) { for (long i = 0; i < n; i++) out[i] = atan(v[i]); }

@@ -85,6 +85,73 @@ def test_glibc_differs_only_by_its_own_misroundings(crm):
     assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+def _adversarial(rng, n):
+    """Inputs around the table nodes and interval ends of both first stages, next to ordinary ones."""
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, n), rng.uniform(-7, 7, n // 4),
+                         rng.integers(-64, 65, n // 4) * (np.pi / 32) + rng.normal(0, 1, n // 4) * 10.0 ** rng.uniform(-17, -2, n // 4),
+                         (rng.integers(-64, 64, n // 4) + 0.5) * (np.pi / 32) * (1 + rng.normal(0, 1e-6, n // 4))])
+    th = rng.uniform(-np.pi, np.pi, n)
+    r = 10.0 ** rng.uniform(-3, 3, n)
+    i = rng.integers(0, 65, n)
+    d = rng.uniform(0.1, 100, n)
+    g1 = rng.integers(-510, 511, n) / 2.0 * rng.uniform(0, 1, n)          # gradient-like: halves of small integers
+    g2 = rng.integers(-510, 511, n) / 2.0
+    ys = np.concatenate([rng.normal(0, 10, n), np.sin(th) * r, rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-12, 3, n),
+                         d * (i / 64.0) * (1 + rng.normal(0, 1, n) * 10.0 ** rng.uniform(-17, -3, n)) * rng.choice([-1, 1], n),
+                         d * ((i + 0.5) / 64.0) * (1 + rng.normal(0, 1e-6, n)), g1, g2])
+    xx = np.concatenate([rng.normal(0, 10, n), np.cos(th) * r, rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-12, 3, n),
+                         d * rng.choice([-1, 1], n), d * rng.choice([-1, 1], n), g2, g1])
+    return xs, ys, xx
+
+
+def test_first_stage_equals_the_full_evaluation(crm):
+    """sincos_fast / atan2_fast (Ziv's first stage, what the gradient pass runs for nearly every pixel) answer only when the
+    rounding is certain: every answer must equal the double-double evaluation bit for bit, and nearly all calls are answered."""
+    crm.crm_sincos_fast_n.restype = C.c_long
+    crm.crm_atan2_fast_n.restype = C.c_long
+    xs, ys, xx = _adversarial(np.random.default_rng(21), 1_500_000)
+    bad = C.c_long()
+    acc = crm.crm_sincos_fast_n(P(xs), C.c_long(len(xs)), C.byref(bad))
+    assert bad.value == 0 and acc > 0.99 * len(xs)
+    acc = crm.crm_atan2_fast_n(P(ys), P(xx), C.c_long(len(ys)), C.byref(bad))
+    assert bad.value == 0 and acc > 0.99 * len(ys)
+    # ordinary inputs: the second stage is needed about once in 10^4 calls
+    rng = np.random.default_rng(22)
+    u = rng.uniform(-np.pi, np.pi, 2_000_000)
+    assert crm.crm_sincos_fast_n(P(u), C.c_long(len(u)), C.byref(bad)) > (1 - 5e-4) * len(u) and bad.value == 0
+    a, b = rng.normal(0, 10, 2_000_000), rng.normal(0, 10, 2_000_000)
+    assert crm.crm_atan2_fast_n(P(a), P(b), C.c_long(len(a)), C.byref(bad)) > (1 - 5e-4) * len(a) and bad.value == 0
+
+
+def test_first_stage_error_is_well_inside_its_bound(crm):
+    """The unrounded first-stage values against mpmath: the error must stay below a quarter of the bound the rounding test
+    assumes (2^-68 relative, + 2^-99 absolute for sin/cos)."""
+    import mpmath as mp
+    mp.mp.prec = 200
+    xs, ys, xx = _adversarial(np.random.default_rng(23), 4000)
+    o = np.zeros(6 * len(xs))
+    crm.crm_sincos_fast_raw_n(P(xs), P(o), C.c_long(len(xs)))
+    worst = 0.0
+    for x, row in zip(xs, o.reshape(-1, 6)):
+        if x == 0 or abs(x) > 64:
+            continue
+        X = mp.mpf(float(x))
+        for h, l, f in ((row[1], row[2], mp.sin), (row[3], row[4], mp.cos)):
+            e = abs(mp.mpf(float(h)) + mp.mpf(float(l)) - f(X))
+            worst = max(worst, float(e / (abs(mp.mpf(float(h))) * mp.mpf(2) ** -68 + mp.mpf(2) ** -99)))
+    assert worst < 0.25, worst
+    o = np.zeros(3 * len(ys))
+    crm.crm_atan2_fast_raw_n(P(ys), P(xx), P(o), C.c_long(len(ys)))
+    worst = 0.0
+    for y, x, row in zip(ys, xx, o.reshape(-1, 3)):
+        if row[1] == 0 and row[2] == 0:                             # declined before evaluating (zeros, extremes)
+            continue
+        t = abs(mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))))
+        e = abs(mp.mpf(float(row[1])) + mp.mpf(float(row[2])) - t)
+        worst = max(worst, float(e / (abs(mp.mpf(float(row[1]))) * mp.mpf(2) ** -68)))
+    assert worst < 0.25, worst
+
+
 @pytest.mark.gpu
 def test_device_build_matches_host_build(crm, lsdmod):
     ctx = lsdmod.Context(0)
