@@ -67,14 +67,15 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
         for (int i = lane; i < cnt; i += GX) {
             const uint32_t e = l_px[i];
             const double2 gr = l_g[i];
-            double d = atan2_g(gr.x, -gr.y);                   // :169
+            double d;                                          // :169 (first stage inline, second stage out of line: devmath.h)
+            if (!crm::atan2_fast(gr.x, -gr.y, d)) d = atan2_g(gr.x, -gr.y);
             if (fabs(d - kPi) < 0.000001) d = 0;               // :170-171
             l_g[i] = make_double2(d, 0.0);
             if (e & 1u) {                                      // sin/cos(deg) for RegionGrower (:545-546)
                 const int lt = (int)(e >> 1);
                 const size_t p = base + (size_t)(y0 + lt / GX) * w + ((int)bx * GX + lt % GX);
                 double sv, cv;
-                sincos_g(d, sv, cv);
+                if (!crm::sincos_fast(d, sv, cv)) sincos_g(d, sv, cv);
                 sc[p] = make_double2(sv, cv);
             }
         }
