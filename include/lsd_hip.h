@@ -164,6 +164,10 @@ int lsd_set_trace(lsd_ctx *ctx, int on);
  * image, images taken heaviest first).  0 (default) picks 8 while the batch has at most four images per CU (the step is
  * bounded by its heaviest image until then) and 4 beyond.  Results do not depend on the choice. */
 int lsd_set_region_waves(lsd_ctx *ctx, int waves);
+/* Test hook: the region stage marks the pixels of the region it is growing with a fresh 32-bit id per grow; a wavefront that
+ * uses up its 2^20 ids within one run clears its stamp array and starts over.  That takes more than a million grows by one
+ * wavefront on one image; this lowers the budget (2 .. 0xFFFF0 grows) so that tests reach the path.  Results do not change. */
+int lsd_debug_set_stamp_budget(lsd_ctx *ctx, unsigned grows);
 
 /* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
  *   GAUSS/MAG/DEG  h*w doubles      (GaussImage / magMap / degMap, myLSD.cpp:143-147)

@@ -93,6 +93,7 @@ struct RCtx {
     const double2* sc;   // (sin, cos)(deg)
     int tilesX;
     uint32_t id_base;
+    uint32_t id_budget;  // grows a wave may stamp before it has to clear its stamps (< 2^20: the next run's ids start there)
     double logNT;
     const double* lgamma;
     const double* ptab;
@@ -375,7 +376,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
         }
     }
     uint32_t id = (uint32_t)uni((int)g_ws[wave].cur_id);
-    if ((id - (uint32_t)uni((int)c.id_base)) >= 0xFFFF0u) {                      // the run's 2^20 stamp ids are used up: start over on clean stamps
+    if ((id - (uint32_t)uni((int)c.id_base)) >= (uint32_t)uni((int)c.id_budget)) {                      // the run's 2^20 stamp ids are used up: start over on clean stamps
         for (size_t q = lane; q < (size_t)w * h; q += 64) stamp[q] = 0u;
         wg_fence();
         id = c.id_base;
@@ -1190,7 +1191,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     c.stamp = b.stamps + (img * NW + wave) * npx;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
     c.meta = b.wmeta + (img * NW + wave) * (size_t)b.mcap; c.mcap = b.mcap;
-    c.tilesX = (w + 7) >> 3; c.id_base = id_base;
+    c.tilesX = (w + 7) >> 3; c.id_base = id_base; c.id_budget = b.id_budget;
     if (lane == 0) {
         WState& ws = g_ws[wave];
         ws.cur_id = id_base; ws.gnum = 0; ws.has_copy = 0; ws.dirty = 0; ws.cache_epoch = -1; ws.members_cached = 0;

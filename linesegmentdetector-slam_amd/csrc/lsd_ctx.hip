@@ -20,6 +20,7 @@ using namespace lsdhip;
 struct lsd_ctx {
     int device = 0;
     int num_cus = 256;                 // compute units of the device
+    uint32_t id_budget = 0xFFFF0u;     // curMap stamp ids a wave may use per run before it clears its stamps (lsd_debug_set_stamp_budget)
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     hipStream_t stream = nullptr;      // the context's own stream
     hipStream_t last_stream = nullptr; // stream of the last enqueue
@@ -351,6 +352,12 @@ int lsd_set_region_waves(lsd_ctx* c, int waves) {
     return LSD_OK;
 }
 
+int lsd_debug_set_stamp_budget(lsd_ctx* c, unsigned grows) {
+    if (!c || grows < 2u || grows > 0xFFFF0u) return LSD_ERR_INVALID;
+    c->id_budget = grows;
+    return LSD_OK;
+}
+
 int lsd_set_trace(lsd_ctx* c, int on) {
     if (!c) return LSD_ERR_INVALID;
     c->trace = on != 0;
@@ -388,7 +395,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
-    b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.pend = c->pend; b.rnum = c->rnum;
+    b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;

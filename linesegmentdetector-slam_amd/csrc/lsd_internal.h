@@ -61,6 +61,7 @@ struct Buffers {
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
+    uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)

@@ -628,6 +628,50 @@ def test_region_stage_variants_agree(maps, lsdmod, ctx, oracle):
         assert a[1][i + 1] - a[1][i] == len(oracle.lsd(imgs[i].copy())["lines"])
 
 
+def _sawtooth(name):
+    if name == "saw_x":                                                      # bands of ~36 x 450 scaled pixels, one angle each
+        yy, xx = np.mgrid[0:1500, 0:900]
+        return ((xx % 120) * 255 // 119).astype(np.uint8)
+    if name == "saw_diag":
+        yy, xx = np.mgrid[0:1200, 0:1000]
+        return (((xx + yy) % 170) * 255 // 169).astype(np.uint8)
+    if name == "saw_tall":                                                   # more than 65535 pixels per region
+        yy, xx = np.mgrid[0:7000, 0:400]
+        return ((xx % 120) * 255 // 119).astype(np.uint8)
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:1200, 0:900]
+    return np.clip((xx % 120) * 255.0 / 119 + rng.normal(0, 3, xx.shape), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["saw_x", "saw_diag", "saw_tall", "saw_noise"])
+def test_giant_regions_match_oracle(name, lsdmod, ctx, oracle):
+    """Occupancy maps have thin walls; a sawtooth image has regions of tens of thousands of pixels instead.  They leave every
+    fast structure of the region stage (LDS list -> HBM spill, worklists and skip filter given up, 16-bit worklist indices
+    exceeded, result slots too small for the examined list) and must still give the reference's answer, with either build."""
+    img = _sawtooth(name)
+    try:
+        for waves in (4, 8):
+            ctx.set_region_waves(waves)
+            lines, _, ref = full_check(lsdmod, ctx, oracle, img)
+            assert len(lines) > 0 and ref["dbg"]["grown_px"] > 20000
+    finally:
+        ctx.set_region_waves(0)
+
+
+def test_stamp_ids_running_out_changes_nothing(maps, lsdmod, ctx, oracle):
+    """A wavefront that uses up its 2^20 curMap stamp ids inside one run clears its stamps and starts over; with the budget
+    lowered to a few grows every image takes that path hundreds of times."""
+    img = np.ascontiguousarray(maps["aisle2"][:700, :1500])
+    try:
+        for waves, budget in ((4, 7), (8, 3), (8, 64)):
+            ctx.set_region_waves(waves)
+            ctx.debug_set_stamp_budget(budget)
+            full_check(lsdmod, ctx, oracle, img)
+    finally:
+        ctx.debug_set_stamp_budget(0xFFFF0)
+        ctx.set_region_waves(0)
+
+
 def test_map_cache_many_small_maps_one_workgroup_each(lsdmod, ctx, oracle):
     """More than 64 maps take the one-workgroup-per-map kernel (fewer take the kernel-per-level one): same answers."""
     import torch
