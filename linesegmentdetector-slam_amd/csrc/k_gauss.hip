@@ -30,7 +30,7 @@ __device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 
 template <int HS>
 __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
                                               const double* __restrict__ taps_g, int W, int H, int w, int h, int gp,
-                                              double sca, int tapR, int IWp, int IHmax) {
+                                              double sca, int tapR, int IWp, int IHmax, unsigned gx, unsigned gy, unsigned tiles) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int hSize = HS > 0 ? HS : 2 * tapR + 1;
     double* aux = reinterpret_cast<double*>(smem);                // [IHmax][TW]
@@ -38,8 +38,15 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     uint8_t* tile = reinterpret_cast<uint8_t*>(taps + 3 * hSize); // [IHmax][IWp]
 
     const int tid = threadIdx.x;
-    const int X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
-    const size_t img = blockIdx.z;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2): the tiles are numbered
+    // such that one XCD walks a contiguous eighth of the batch, so the 15-pixel halo a tile shares with its neighbours comes out
+    // of the L2 the neighbouring tile has just filled.
+    const unsigned per = (tiles + 7u) >> 3;
+    const unsigned t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (t >= tiles) return;
+    const unsigned bx = t % gx, tq = t / gx, by = tq % gy;
+    const int X0 = (int)bx * TW, Y0 = (int)by * TH;
+    const size_t img = tq / gy;
     const uint8_t* src = in + img * (size_t)W * H;
     double* dst = out + img * (size_t)gp * h;                     // rows padded to gp doubles (128-byte aligned rows for K2)
 
@@ -193,8 +200,9 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     auto kern = hSize == 17 ? k_gauss<17> : k_gauss<0>;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((g.w + TW - 1) / TW, (g.h + TH - 1) / TH, n);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.gp, g.sca, g.tapR, IWp, IHmax);
+    const unsigned gx = (g.w + TW - 1) / TW, gy = (g.h + TH - 1) / TH, tiles = gx * gy * (unsigned)n;
+    hipLaunchKernelGGL(kern, dim3(((tiles + 7u) >> 3) * 8u), dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.gp, g.sca,
+                       g.tapR, IWp, IHmax, gx, gy, tiles);
 }
 
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {
