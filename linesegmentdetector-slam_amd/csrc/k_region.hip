@@ -435,9 +435,16 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
     auto batch = [&](int cnt, const int eidx, const bool direct, const float Cf, const float Sf, const float rV, const float Vn,
                      const float nrat) -> int {
         bool valid = e < cnt;
-        uint32_t pk;
-        if (direct) pk = g_lst[wave][eidx];              // (entries past n: harmless garbage, masked by valid)
-        else pk = valid ? lget(c, eidx) : 0u;
+        // (entries past n: harmless garbage, masked by valid.)  The LDS part of the list is read unconditionally and the HBM part
+        // in a block of its own that also waits for it: a load whose register is still pending at the join would make the
+        // compiler put an s_waitcnt vmcnt(0) in front of every batch, and that waits for the stamp stores of the batch before.
+        uint32_t pk = g_lst[wave][direct ? eidx : min(eidx, LCAP - 1)];
+        if (!direct && ballot64(valid & (eidx >= LCAP))) {
+            uint32_t t = pk;
+            if (valid & (eidx >= LCAP)) t = c.spill[eidx - LCAP];
+            asm volatile("; spilled list entry %0" :: "v"(t));
+            pk = t;
+        }
         const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
         bool inb = valid & ((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h);   // :536 (plain &: no short-circuit branches)
         const int tx = nx >> 3, ty = ny >> 3;
