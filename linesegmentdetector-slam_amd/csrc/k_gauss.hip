@@ -132,6 +132,9 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
                 for (int r = tid / TW; r < IH; r += NT / TW) {
                     const uint32_t* t4 = trow + r * DWp;
                     const uint32_t d0 = t4[0], d1 = t4[1], d2 = t4[2], d3 = t4[3], d4 = t4[4];
+                    // occupancy maps are mostly zeros after the remap (free and unknown cells): where the whole wavefront sees
+                    // zeros the sum is +0.0 exactly (every term is +0.0 * tap = +0.0, and +0.0 + +0.0 = +0.0)
+                    if (__ballot((d0 | d1 | d2 | d3 | d4) != 0u) == 0ull) { aux[r * TW + X] = 0.0; continue; }
                     uint32_t wv[5];
                     wv[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); wv[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
                     wv[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); wv[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
