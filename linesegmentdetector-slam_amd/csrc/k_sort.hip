@@ -49,10 +49,19 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     __syncthreads();
 
     uint32_t* myh = hist + wave * pseBin;
-    for (int base = beg; base < end; base += 64) {
-        const int p = base + lane;
-        const int v = p < end ? bin_of(m[p], zoom, pseBin) : 0;
-        if (v != 0) atomicAdd(&myh[pseBin - v], 1u);
+    constexpr int UN = 4;                                          // 64-pixel chunks per step: independent loads in flight per wave
+    for (int base = beg; base < end; base += 64 * UN) {
+        double mv[UN];
+        #pragma unroll
+        for (int j = 0; j < UN; j++) {
+            const int p = base + 64 * j + lane;
+            mv[j] = p < end ? m[p] : 0.0;
+        }
+        #pragma unroll
+        for (int j = 0; j < UN; j++) {
+            const int v = bin_of(mv[j], zoom, pseBin);             // (0.0 gives bin 0)
+            if (v != 0) atomicAdd(&myh[pseBin - v], 1u);
+        }
     }
     __syncthreads();
 
@@ -82,24 +91,33 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     __syncthreads();
 
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = beg; base < end; base += 64) {
-        const int p = base + lane;
-        const int v = p < end ? bin_of(m[p], zoom, pseBin) : 0;
-        const int b = pseBin - v;
-        unsigned long long act = __ballot(v != 0);
-        while (act) {
-            const int l = __builtin_ctzll(act);
-            const int bsel = __builtin_amdgcn_readlane(b, l);
-            const bool mine = (v != 0) && (b == bsel);
-            const unsigned long long mm = __ballot(mine);
-            const uint32_t start = myh[bsel];
-            if (mine) {
-                const uint32_t r = start + (uint32_t)__builtin_popcountll(mm & lt);
-                o[r] = (uint32_t)p;
-                ov[r] = (uint16_t)v;
+    for (int base = beg; base < end; base += 64 * UN) {
+        double mv[UN];
+        #pragma unroll
+        for (int j = 0; j < UN; j++) {
+            const int p = base + 64 * j + lane;
+            mv[j] = p < end ? m[p] : 0.0;
+        }
+        #pragma unroll
+        for (int j = 0; j < UN; j++) {                             // chunks in raster order
+            const int p = base + 64 * j + lane;
+            const int v = bin_of(mv[j], zoom, pseBin);
+            const int b = pseBin - v;
+            unsigned long long act = __ballot(v != 0);
+            while (act) {
+                const int l = __builtin_ctzll(act);
+                const int bsel = __builtin_amdgcn_readlane(b, l);
+                const bool mine = (v != 0) && (b == bsel);
+                const unsigned long long mm = __ballot(mine);
+                const uint32_t start = myh[bsel];
+                if (mine) {
+                    const uint32_t r = start + (uint32_t)__builtin_popcountll(mm & lt);
+                    o[r] = (uint32_t)p;
+                    ov[r] = (uint16_t)v;
+                }
+                if (lane == l) myh[bsel] = start + (uint32_t)__builtin_popcountll(mm);
+                act &= ~mm;
             }
-            if (lane == l) myh[bsel] = start + (uint32_t)__builtin_popcountll(mm);
-            act &= ~mm;
         }
     }
 }
