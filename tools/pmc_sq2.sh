@@ -3,7 +3,7 @@
 #   tools/pmc_sq2.sh <tag> [waves] [image ids...]
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-for set in "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"; do
+for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   n=$(echo $set | cut -d' ' -f1)
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq2_${tag}_$n
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/tools/one_stats.py "$@" > $out.log 2>&1
