@@ -486,7 +486,9 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 const float m = (float)__builtin_popcountll(ballot64(winner));
                 dot = __builtin_fmaf(cf, Cf, sf * Sf);                            // ~ cos(distance) * |V|
                 const float eps_c = kEpsU * (1.0f + 2.1f * nrat) + 5e-6f;         // incl. the error of Vn
-                const float delta = m * turn * rV + 1e-7f;                        // |V| >= 1 here: accepted vectors only lengthen the sum
+                // a candidate is compared with the sum after the winners BEFORE it (at most m - 1) have been added, each turning it by
+                // at most turn / |V| (|V| >= 1 here: accepted vectors only lengthen the sum); a lone candidate sees no drift at all
+                const float delta = (m - 1.0f) * turn * rV + 1e-7f;
                 const float t_hi = delta <= tolf_lo ? (cos_tol + delta * sin_tol + eps_c) * Vn : 3e38f;
                 const float t_lo = delta <= 1.6f ? (cos_tol - delta * fminf(1.0f, sin_tol + delta) - eps_c) * Vn : -3e38f;
                 const unsigned long long pcm = ballot64(cand & (dot > t_hi));     // candidates that clearly pass
