@@ -124,6 +124,7 @@ __shared__ int g_ttag[NW][NT];
 __shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
 __shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
+__shared__ double g_tol0[3];                              // the global tolerance (degThre) with its sine and cosine: every first grow uses it
 __shared__ double g_acc[NW][32 * 4];                      // staging of the serial (bit-exact) sums: 32 list elements x up to 4 terms
 
 // The reference's sums over a region (moments, angle sums, Refiner's statistics) are plain left-to-right fp64 additions, and
@@ -413,7 +414,8 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
     float cos_tol, sin_tol;
     {
         double st, ct;
-        sincos_g(tol_small ? tol : 1.0, st, ct);
+        if (tol == g_tol0[0]) { st = g_tol0[1]; ct = g_tol0[2]; }           // (wave-uniform)
+        else sincos_g(tol_small ? tol : 1.0, st, ct);
         cos_tol = (float)ct; sin_tol = (float)st * 1.0000002f + 1e-7f;      // sin_tol >= sin(tol)
     }
     const int e = lane >> 3, k = lane & 7;
@@ -523,6 +525,19 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 DSTAT(ST_SLOW, 1);
                 unsigned long long todo = candm;
                 while (todo) {
+                    if (tol_small) {
+                        // All candidates still to come, against the estimate as it stands: the ones that clearly fail BEFORE the
+                        // first one that does not are decided for good (nothing is accepted in between, so this is the estimate
+                        // they meet at their turn) -- the loop runs once per accepted pixel, not once per candidate.
+                        const float Cg0 = (float)Ce, Sg0 = (float)Se;
+                        const float Vg0 = __builtin_amdgcn_sqrtf(Cg0 * Cg0 + Sg0 * Sg0) * 1.000001f;
+                        const float nr0 = (float)n * inv_ub(fmaxf(Vg0, 1e-3f));
+                        const float ec0 = kEpsU * (1.0f + 2.1f * nr0) + 5e-6f;
+                        const unsigned long long failm0 = ballot64((cf * Cg0 + sf * Sg0) < (cos_tol - ec0) * Vg0);
+                        const unsigned long long nf = todo & ~(failm0 | gone);
+                        if (!nf) break;                  // everything left fails
+                        todo &= ~((1ull << __builtin_ctzll(nf)) - 1ull);
+                    }
                     const int l = __builtin_ctzll(todo);
                     todo &= todo - 1ull;
                     if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
@@ -613,7 +628,9 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
         ex = n;
         nxt_cnt = 0;
         int i = n;                                           // contiguous cursor: the entries appended during this sweep ...
-        if (sweep == 1 || !filter) i = 0;                    // ... or the whole list (first sweep; worklists given up)
+        // ... or the whole list: the first sweep; worklists given up; and a region of up to 8 pixels -- one batch sweeps it
+        // again, which costs less than fetching the slack records of its worklist (most regions are this small)
+        if (sweep == 1 || !filter || n <= 8) i = 0;
         else {
             // ---- entries of earlier sweeps that still had a growable non-member neighbour ----
             int wi = 0;                                      // worklist cursor
@@ -673,7 +690,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
         wl_cnt = nxt_cnt;
         sweep++;
         flt_valid = false;
-        if (n != ex) wg_fence();                             // meta[] written in this sweep is read in the next
+        if (n != ex && n > 8) wg_fence();                    // meta[] written in this sweep is read in the next
     } while (n != ex);
 #undef GROW_ESTIMATE
     if (lane == 0) g_ws[wave].gnum = n;
@@ -1220,6 +1237,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     SeedRec* trace = b.seeds ? reinterpret_cast<SeedRec*>(b.seeds) + img * npx : nullptr;
     int* rnum = b.rnum + img * (size_t)RW * 2;            // (num0, final_num << 2 | outcome) of published records: read by the seed trace only
 
+    if (wave == NW - 1) {
+        double st, ct;
+        sincos_g(g.degThre < 1.5 ? g.degThre : 1.0, st, ct);
+        if (lane == 0) { g_tol0[0] = g.degThre; g_tol0[1] = st; g_tol0[2] = ct; }
+    }
     // potential seeds: sorted entries whose pixel is not below the gradient threshold (usedMap == 0 after K2)
     if (wave == 0) {
         int cnt = 0;
