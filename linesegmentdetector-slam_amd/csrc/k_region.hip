@@ -1415,6 +1415,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
     int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
+    int win_k0 = -64;                                      // window of seeds in registers (see the seed loop)
+    uint32_t win_pp = 0u;
+    unsigned long long win_used = 0ull;
     const unsigned long long ltm = (1ull << lane) - 1ull;
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
@@ -1452,8 +1455,17 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 }
             }
         }
-        const int oidx = (int)seedidx[k];
-        const uint32_t pp = ord[oidx];
+        // The seed's pixel comes out of a window of 64 consecutive seeds kept in registers (lane j: seed win_k0 + j): three
+        // dependent loads (seed index -> sorted list -> pixel word) per 64 seeds instead of per seed, and the seeds already used
+        // when the window was loaded -- two thirds of them on the bench maps, once used is always used (:222) -- cost no load at all.
+        if (k < win_k0 || k >= win_k0 + 64) {
+            win_k0 = k;
+            const bool wv = k + lane < nseeds;
+            win_pp = wv ? ord[seedidx[k + lane]] : 0u;
+            win_used = ballot64(wv && (c.pw[win_pp] & 3u) != 0u);
+        }
+        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)win_pp, k - win_k0);
+        const bool skip_known = ((win_used >> (k - win_k0)) & 1ull) != 0ull;
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
         int outcome = 0, num = 0, num0 = 0;
@@ -1468,7 +1480,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             invalidate_tiles(c);
             g_ws[wave].cache_epoch = epoch_snap;
         }
-        const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
+        const bool skip = skip_known || (c.pw[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
         uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
