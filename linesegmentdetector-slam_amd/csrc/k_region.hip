@@ -525,42 +525,42 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                 DSTAT(ST_SLOW, 1);
                 unsigned long long todo = candm;
                 while (todo) {
+                    int l, decided = -1;                 // 1 take, 0 reject, -1 exact test needed
                     if (tol_small) {
                         // All candidates still to come, against the estimate as it stands: the ones that clearly fail BEFORE the
                         // first one that does not are decided for good (nothing is accepted in between, so this is the estimate
                         // they meet at their turn) -- the loop runs once per accepted pixel, not once per candidate.
-                        const float Cg0 = (float)Ce, Sg0 = (float)Se;
-                        const float Vg0 = __builtin_amdgcn_sqrtf(Cg0 * Cg0 + Sg0 * Sg0) * 1.000001f;
-                        const float nr0 = (float)n * inv_ub(fmaxf(Vg0, 1e-3f));
-                        const float ec0 = kEpsU * (1.0f + 2.1f * nr0) + 5e-6f;
-                        const unsigned long long failm0 = ballot64((cf * Cg0 + sf * Sg0) < (cos_tol - ec0) * Vg0);
-                        const unsigned long long nf = todo & ~(failm0 | gone);
-                        if (!nf) break;                  // everything left fails
-                        todo &= ~((1ull << __builtin_ctzll(nf)) - 1ull);
-                    }
-                    const int l = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
-                    const float cl = rlf(cf, l), sl = rlf(sf, l);
-                    const float Cg = (float)Ce, Sg = (float)Se;
-                    const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
-                    const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
-                    int decided = -1;                    // 1 take, 0 reject, -1 exact test needed
-                    if (tol_small) {
-                        const float d1 = cl * Cg + sl * Sg;
+                        const float Cg = (float)Ce, Sg = (float)Se;
+                        const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
+                        const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
                         const float ec = kEpsU * (1.0f + 2.1f * nr) + 5e-6f;
-                        if (d1 > (cos_tol + ec) * Vg) decided = 1;
-                        else if (d1 < (cos_tol - ec) * Vg) decided = 0;
-                    } else if (Vg > 0.05f) {
-                        // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
-                        const double R = n == 1 ? regDeg0 : atan2(Se, Ce);
-                        const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
-                        const double al = (double)rlf(af, l);
-                        const double rw = fabs(R - al);
-                        const double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
-                        if (!(fabs(R) > kPi - er || fabs(df - tol) <= er || fabs(rw - kPi * 3 / 2.0) <= er)) decided = df < tol ? 1 : 0;
+                        const float d1 = cf * Cg + sf * Sg;
+                        const unsigned long long failm1 = ballot64(d1 < (cos_tol - ec) * Vg);
+                        const unsigned long long passm1 = ballot64(d1 > (cos_tol + ec) * Vg);
+                        const unsigned long long nf = todo & ~(failm1 | gone);
+                        if (!nf) break;                  // everything left fails
+                        l = __builtin_ctzll(nf);
+                        todo &= ~((2ull << l) - 1ull);   // (l < 63 or the mask is all ones: 2 << 63 wraps to 0)
+                        if ((passm1 >> l) & 1ull) decided = 1;
+                    } else {
+                        l = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        if ((gone >> l) & 1ull) continue;    // the same pixel was accepted a moment ago
+                        const float Cg = (float)Ce, Sg = (float)Se;
+                        const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
+                        const float nr = (float)n * inv_ub(fmaxf(Vg, 1e-3f));
+                        if (Vg > 0.05f) {
+                            // any tolerance: the reference's wrapped difference (:540-542) of estimates, exact when near a discontinuity
+                            const double R = n == 1 ? regDeg0 : atan2(Se, Ce);
+                            const double er = (n == 1 ? 0.0 : (double)(1.05f * kEpsU * nr) + 1e-7) + 1.2e-6;   // + the packed angle's own error
+                            const double al = (double)rlf(af, l);
+                            const double rw = fabs(R - al);
+                            const double df = rw > kPi * 3 / 2.0 ? fabs(rw - 2.0 * kPi) : rw;
+                            if (!(fabs(R) > kPi - er || fabs(df - tol) <= er || fabs(rw - kPi * 3 / 2.0) <= er)) decided = df < tol ? 1 : 0;
+                        }
+                        decided = uni(decided);          // (the same in every lane; computed on the vector unit)
                     }
-                    decided = uni(decided);              // (the same in every lane; computed on the vector unit)
+                    const float cl = rlf(cf, l), sl = rlf(sf, l);
                     const int ql = __builtin_amdgcn_readlane(q, l);
                     if (decided < 0) {
                         exact_sums(c, n);
