@@ -124,6 +124,8 @@ __shared__ int g_ttag[NW][NT];
 __shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
 __shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
+__shared__ RCtx g_ctx[NW];                                // the wave's context: the out-of-line stages get the wave number and read it here
+                                                          // (a struct passed by value travels through scratch memory at every call)
 __shared__ double g_tol0[3];                              // the global tolerance (degThre) with its sine and cosine: every first grow uses it
 __shared__ double g_acc[NW][32 * 4];                      // staging of the serial (bit-exact) sums: 32 list elements x up to 4 terms
 
@@ -290,7 +292,9 @@ __device__ __forceinline__ void invalidate_tiles(const RCtx& c) {
 // ---------------------------------------------------------------------------------------------
 // (out of line, like every per-region stage below: each gets the register file to itself, and the seed loop keeps only
 //  what it needs across the calls; the context travels by value, the mutable state sits in LDS)
-__device__ __noinline__ void exact_sums(RCtx c, int n_) {
+__device__ __noinline__ void exact_sums(int cw_, int n_) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int wave = __builtin_amdgcn_readfirstlane(c.wave), n = __builtin_amdgcn_readfirstlane(n_);
     const int from = __builtin_amdgcn_readfirstlane(g_ws[wave].ex_upto);
     if (from >= n) return;
@@ -354,7 +358,9 @@ __device__ __forceinline__ void fast_sincos(float a, float& s, float& co) {   //
     co = __builtin_amdgcn_cosf(r);
 }
 
-__device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, double tol_) {
+__device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, double tol_) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int lane = c.lane;
     const double regDeg0 = uni(regDeg0_), tol = uni(tol_);
     const int w = uni(c.w), h = uni(c.h), wave = uni(c.wave), mcap = uni(c.mcap);
@@ -563,7 +569,7 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
                     const float cl = rlf(cf, l), sl = rlf(sf, l);
                     const int ql = __builtin_amdgcn_readlane(q, l);
                     if (decided < 0) {
-                        exact_sums(c, n);
+                        exact_sums(c.wave, n);
                         const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
                         DSTAT(ST_EXACT, 1);
                         decided = uni(angle_diff(R, c.deg[ql]) < tol ? 1 : 0);              // :540-543
@@ -703,7 +709,9 @@ __device__ __noinline__ int grow(RCtx c, int sx_, int sy_, double regDeg0_, doub
 // ---------------------------------------------------------------------------------------------
 // CenterGetter (:592-619) + OrientationGetter (:621-667) + RectangleConverter (:669-734)
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void rect_convert(RCtx c, int num, double regdeg, double aliPro, int pk, double tol) {
+__device__ __noinline__ void rect_convert(int cw_, int num, double regdeg, double aliPro, int pk, double tol) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int lane = c.lane, w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
@@ -798,14 +806,18 @@ __device__ __forceinline__ double rec_density(int num, const Rec& r) {          
 // RegionRadiusReducer, myLSD.cpp:736-802 (incl. the `i <= num` sentinel behaviour)
 // ---------------------------------------------------------------------------------------------
 // Returns the new region size, or -(size + 1) when the region is given up (:792).  The rectangle is g_ws[c.wave].rec.
-__device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, double regdeg, double denThre);
-__device__ __noinline__ int radius_reduce(RCtx c, int sx, int sy, int num, double regdeg, double denThre) {
+__device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num, double regdeg, double denThre);
+__device__ __noinline__ int radius_reduce(int cw_, int sx, int sy, int num, double regdeg, double denThre) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     [[maybe_unused]] const long long t0 = NOW();
-    const int r = radius_reduce_impl(c, sx, sy, num, regdeg, denThre);
+    const int r = radius_reduce_impl(c.wave, sx, sy, num, regdeg, denThre);
     DSTAT(ST_TRRR, NOW() - t0);
     return r;
 }
-__device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, double regdeg, double denThre) {
+__device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num, double regdeg, double denThre) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int lane = c.lane, w = c.w;
     STAT(ST_RRR, 1);
     double den = rec_density(num, g_ws[c.wave].rec);
@@ -918,7 +930,7 @@ __device__ __noinline__ int radius_reduce_impl(RCtx c, int sx, int sy, int num, 
             i++;
         }
         if (num < 2) return -(num + 1);                                            // :792
-        rect_convert(c, num, regdeg, rec.p, rec.pk, rec.prec);                     // :797 (p, prec unchanged)
+        rect_convert(c.wave, num, regdeg, rec.p, rec.pk, rec.prec);                     // :797 (p, prec unchanged)
         den = rec_density(num, g_ws[c.wave].rec);
     }
     return num;
@@ -1045,7 +1057,9 @@ __device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec) {
 
 // RectangleImprover, myLSD.cpp:1061-1158.  The reference's five hand-unrolled phases are walked by one
 // loop (step 0 = the initial evaluation, then 5 phases x 5 tries) so that the NFA code is inlined once.
-__device__ __noinline__ double improve(RCtx c) {
+__device__ __noinline__ double improve(int cw_) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const double delt = 0.5, delt2 = delt / 2.0;
     Rec best = g_ws[c.wave].rec, r = best;
     double bestNFA = 0;
@@ -1085,7 +1099,9 @@ __device__ __noinline__ double improve(RCtx c) {
 // Refiner, myLSD.cpp:804-880, first half: the re-estimated angle tolerance (:833-855).  The regrow (:857),
 // the refit (:866) and the density checks are in the caller's two-pass loop so that grow() and
 // rect_convert() are inlined once.
-__device__ __noinline__ double refine_tol(RCtx c, int sx, int sy, int num, double cenDeg) {
+__device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, double cenDeg) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int lane = c.lane, w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
     const double rwid = g_ws[c.wave].rec.wid;
@@ -1132,7 +1148,9 @@ __device__ __noinline__ double refine_tol(RCtx c, int sx, int sy, int num, doubl
 // epoch1 == 0: a rejected region (usedMap = 2); else an accepted line of epoch epoch1 - 1 (usedMap = 1).
 struct Box { int x0, y0, x1, y1; };
 
-__device__ __noinline__ Box mark_region(RCtx c, uint32_t epoch1, const uint32_t* src, int src_cnt) {
+__device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t* src, int src_cnt) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     const int w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
     wg_fence();                                   // the stamps written by grow() must have landed
@@ -1162,7 +1180,9 @@ __device__ __noinline__ Box mark_region(RCtx c, uint32_t epoch1, const uint32_t*
 }
 
 // bounding box of `in` and the first num pixels of the region list (of the grow-order copy when from_copy)
-__device__ __noinline__ Box list_bbox(RCtx c, int num, Box in, bool from_copy) {
+__device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) {
+    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
+    c.lane = (int)(threadIdx.x & 63u);
     int x0 = in.x0, y0 = in.y0, x1 = in.x1, y1 = in.y1;
     for (int k2 = c.lane; k2 < num; k2 += 64) {
         const uint32_t pkx = from_copy ? c.gcopy[k2] : lget(c, k2);
@@ -1224,6 +1244,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
     }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
+    if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
     if (lane < ST_COUNT) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
     if (lane < NT) g_ttag[c.wave][lane] = -1;
@@ -1310,14 +1331,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     auto commit_marks = [&](int k, int num0, int fnum, int outcome, double logNFA, double pv, const uint32_t* m_src, int m_cnt) {
         write_trace(k, num0, fnum, outcome, logNFA);
         if (outcome == 2) {                                                          // :242-250
-            (void)mark_region(c, 0u, m_src, m_cnt);
+            (void)mark_region(c.wave, 0u, m_src, m_cnt);
         } else if (outcome == 3) {
             const int li = s_lines;
             if (li < b.max_lines) {
                 if (lane < 12) recs[(size_t)li * 12 + lane] = pv;                    // structRec as accepted
                 if (lane < 4) recs_scaled[(size_t)li * 4 + lane] = g.sca != 1 ? (pv - 1.0) / g.sca + 1 : pv;   // x1 y1 x2 y2, :252-258
             }
-            const Box mb = mark_region(c, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
+            const Box mb = mark_region(c.wave, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
             wg_fence();                                   // the marks must be visible before the epoch moves
             if (lane == 0) {
                 const int ep = s_epoch;
@@ -1494,7 +1515,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             double tol = g.degThre, regdeg = seedDeg;
             bool done = false;
             for (int pass = 0; pass < 2 && !done; pass++) {
-                num = grow(c, sx, sy, seedDeg, tol);                                  // :225 / :857
+                num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
                 if (pass == 0 && spec && num <= b.gcap) {              // keep the first list for the validation at the cursor
                     for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
                     n1 = num;
@@ -1504,26 +1525,26 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     num0 = num;
                     if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
                 } else if (num < 2) { outcome = 1; done = true; break; }              // :861
-                if (num > 1) { exact_sums(c, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
+                if (num > 1) { exact_sums(c.wave, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
                 else regdeg = seedDeg;
-                rect_convert(c, num, regdeg, g.aliPro, 0, g.degThre);                 // :232 / :866 (p, prec still the defaults)
+                rect_convert(c.wave, num, regdeg, g.aliPro, 0, g.degThre);                 // :232 / :866 (p, prec still the defaults)
                 const double den = rec_density(num, g_ws[wave].rec);
                 if (pass == 0) {
                     if (den >= g.denThre) break;                                      // :829 dense enough
                     if (spec) {                                                       // the regrow replaces this list
                         Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-                        fb = list_bbox(c, num, fb, false);
+                        fb = list_bbox(c.wave, num, fb, false);
                         fx0 = fb.x0; fy0 = fb.y0; fx1 = fb.x1; fy1 = fb.y1;
                     }
-                    tol = refine_tol(c, sx, sy, num, seedDeg);                        // :833-855
+                    tol = refine_tol(c.wave, sx, sy, num, seedDeg);                        // :833-855
                 } else if (den < g.denThre) {                                         // :869-877
-                    const int r = radius_reduce(c, sx, sy, num, regdeg, g.denThre);   // (lst reordered: gcopy holds the grow-order list)
+                    const int r = radius_reduce(c.wave, sx, sy, num, regdeg, g.denThre);   // (lst reordered: gcopy holds the grow-order list)
                     if (r < 0) { num = -r - 1; outcome = 1; done = true; }
                     else num = r;
                 }
             }
             if (!done) {
-                logNFA = improve(c);                                                  // :240
+                logNFA = improve(c.wave);                                                  // :240
                 outcome = logNFA <= 0 ? 2 : 3;                                        // :242
                 pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;
                 rec_pk = g_ws[wave].rec.pk;
@@ -1553,7 +1574,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         int x0, y0, x1, y1;
         {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
             Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-            fb = list_bbox(c, gnum, fb, has_copy);
+            fb = list_bbox(c.wave, gnum, fb, has_copy);
             x0 = fb.x0 - 1; y0 = fb.y0 - 1; x1 = fb.x1 + 1; y1 = fb.y1 + 1;
         }
         bool precise = n1 >= 0;
