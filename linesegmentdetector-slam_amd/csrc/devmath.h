@@ -8,9 +8,16 @@ namespace lsdhip {
 
 // Out of line on purpose: the double-double bodies are ~2-3 KB of code each and the region kernel has to fit the
 // instruction cache; they are called a few times per region, never per pixel of the serial chain.
-__device__ __noinline__ void sincos_g(double x, double& s, double& c) {
-    if (crm::sincos_fast(x, s, c)) return;                     // first stage (Ziv): certain roundings only
-    if (!crm::sincos_cr(x, s, c)) { s = sin(x); c = cos(x); }
+// (the pair comes back in registers: results handed back through references travel through scratch memory)
+__device__ __noinline__ double2 sincos_g2(double x) {
+    double s, c;
+    if (!crm::sincos_fast(x, s, c))                            // first stage (Ziv): certain roundings only
+        if (!crm::sincos_cr(x, s, c)) { s = sin(x); c = cos(x); }
+    return make_double2(s, c);
+}
+__device__ __forceinline__ void sincos_g(double x, double& s, double& c) {
+    const double2 v = sincos_g2(x);
+    s = v.x; c = v.y;
 }
 __device__ inline double sin_g(double x) { double s, c; sincos_g(x, s, c); return s; }
 __device__ inline double cos_g(double x) { double s, c; sincos_g(x, s, c); return c; }
