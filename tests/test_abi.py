@@ -242,3 +242,23 @@ int main() {
     if not torch.cuda.is_available():
         r = subprocess.run([str(exe)], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr      # no GPU here: lsd_error(NO_DEVICE) through the cv::Mat signatures
+
+
+def test_region_kernel_keeps_its_registers_and_stays_out_of_scratch(tmp_path):
+    """The region stage's out-of-line stages get their context from LDS: a struct passed by value travels through scratch
+    memory at every call (it did: 1840 bytes per lane, 7 % of the stage's time).  The compiler's own resource summary of the
+    8-wave kernel must stay at two waves per SIMD (<= 256 VGPRs) with a small scratch frame (return-address saves only)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "linesegmentdetector-slam_amd", "csrc", "k_region.hip")
+    out = str(tmp_path / "k_region_w8.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DLSD_REGION_NW=8",
+                    "-S", "--cuda-device-only", "-o", out, src], check=True, capture_output=True)
+    text = open(out).read()
+    kern = text[text.index("; Kernel info:"):]
+    vgprs = int(re.search(r"; NumVgprs: (\d+)", kern).group(1))
+    scratch = int(re.search(r"; ScratchSize: (\d+)", kern).group(1))
+    occ = int(re.search(r"; Occupancy: (\d+)", kern).group(1))
+    assert vgprs <= 256 and occ >= 2, (vgprs, occ)
+    assert scratch <= 256, scratch
