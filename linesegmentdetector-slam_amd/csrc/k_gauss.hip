@@ -98,13 +98,17 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
                     const int r = rb + ty + 8 * j;
                     if (r < IH) {
                         const uint32_t x = v[j];
-                        // bytes == 1 -> 255, bytes == 255 -> 0 (myLSD.cpp:135-142); row 0 and column 0 keep their raw values (Q2)
-                        uint32_t t1 = x ^ 0x01010101u, t2 = ~x;   // zero bytes mark the two cases
-                        t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
-                        t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
-                        const uint32_t keep = reflect_idx(r0 + r, H) == 0 ? 0xffffffffu : colkeep;
-                        const uint32_t m1 = ((t1 >> 7) * 255u) & ~keep, m255 = ((t2 >> 7) * 255u) & ~keep;
-                        tile32[r * DWp + cw] = (x | m1) & ~m255;
+                        uint32_t o = 0u;                          // (a word of zeros -- unknown cells, most of an occupancy map -- stays zeros)
+                        if (x != 0u) {
+                            // bytes == 1 -> 255, bytes == 255 -> 0 (myLSD.cpp:135-142); row 0 and column 0 keep their raw values (Q2)
+                            uint32_t t1 = x ^ 0x01010101u, t2 = ~x;   // zero bytes mark the two cases
+                            t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
+                            t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
+                            const uint32_t keep = reflect_idx(r0 + r, H) == 0 ? 0xffffffffu : colkeep;
+                            const uint32_t m1 = ((t1 >> 7) * 255u) & ~keep, m255 = ((t2 >> 7) * 255u) & ~keep;
+                            o = (x | m1) & ~m255;
+                        }
+                        tile32[r * DWp + cw] = o;
                     }
                 }
             }
@@ -166,9 +170,14 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
             const double* ker = taps + (gY % 3) * hSize;
             double v = 0;
             if (HS > 0) {
+                double a[HS > 0 ? HS : 1];
+                bool nz = false;
                 #pragma unroll
-                for (int i = 0; i < HS; i++) v += aux[(rb + i) * TW + X] * ker[i];
-
+                for (int i = 0; i < HS; i++) { a[i] = aux[(rb + i) * TW + X]; nz |= a[i] != 0.0; }
+                if (__ballot(nz) != 0ull) {                    // (all zeros: the sum is +0.0, as in the x-pass)
+                    #pragma unroll
+                    for (int i = 0; i < HS; i++) v += a[i] * ker[i];
+                }
             } else {
                 for (int i = 0; i < hSize; i++) v += aux[(rb + i) * TW + X] * ker[i];
             }
