@@ -198,6 +198,21 @@ def test_deterministic(maps, lsdmod, ctx):
     assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
 
 
+def test_batch_is_deterministic_run_to_run(maps, lsdmod, ctx):
+    """Speculation, the commit order and waves finishing in different orders must not show: the same 48-image batch (one
+    image per compute unit, all at once) gives byte-identical records five times in a row."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    batch = bench.make_batch(maps, 48, 1024)
+    ref = None
+    for _ in range(5):
+        lines, offs, ims = ctx.run_batch(batch.copy())
+        cur = (lines.tobytes(), offs.tobytes(), ims.tobytes())
+        if ref is None:
+            ref = cur
+        assert cur == ref
+
+
 def test_non_packed_stride(maps, lsdmod, ctx, oracle):
     img = maps["map1"]
     rows, cols = img.shape
