@@ -1061,7 +1061,8 @@ __device__ __noinline__ double improve(int cw_) {
     RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
     c.lane = (int)(threadIdx.x & 63u);
     const double delt = 0.5, delt2 = delt / 2.0;
-    Rec best = g_ws[c.wave].rec, r = best;
+    Rec& best = g_ws[c.wave].rec;                           // (the best rectangle so far stays in LDS: every lane writes the same values)
+    Rec r = best;
     double bestNFA = 0;
     for (int step = 0; step <= 25; step++) {
         const int phase = step == 0 ? -1 : (step - 1) / 5;
@@ -1092,7 +1093,6 @@ __device__ __noinline__ double improve(int cw_) {
         if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
         else if (v > bestNFA) { bestNFA = v; best = r; }
     }
-    if (c.lane == 0) g_ws[c.wave].rec = best;
     return bestNFA;
 }
 
