@@ -1443,7 +1443,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
 #define LT(i) do { const long long t_ = NOW(); DSTAT((i), t_ - tl); tl = t_; } while (0)
+    bool adv = false;                                      // a record has been published since the cursor was last looked at
     while (true) {
+        // (one call site: the cursor code is inlined once, not once per kind of result)
+        if (adv) { advance(); adv = false; }
         // ---- choose the next job ----
         int k, slot = 0;
         bool spec;
@@ -1468,9 +1471,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (k0 < nseeds) { k = k0; slot = __builtin_ctzll(freem); spec = true; took = true; }
                 }
                 if (!took) {
-                    advance();
                     if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
                     if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(8);   // nothing moved: every slot waits for the cursor, or nothing is left to hand out
+                    adv = true;                            // (look at the cursor again before asking for a job)
                     LT(ST_WAIT);
                     continue;
                 }
@@ -1567,7 +1570,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (skip) {
             if (lane == slot) slot_k_l = -1;               // nothing kept in the slot
             if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
-            advance();
+            adv = true;
             continue;
         }
         // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
@@ -1597,7 +1600,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
             wg_fence();                                    // the lists are in the slot before the record says so
             if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
-            advance();
+            adv = true;
             continue;
         }
         // marks to make: stash the result (record in pend[], the pixels to mark in the list slot); whoever moves the
@@ -1633,7 +1636,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (redo) {
             if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
             STAT(ST_REDO, 1);
-            advance();
+            adv = true;
             continue;
         }
         if (lane < 12) wave_pend[slot * 24 + lane] = pv;
@@ -1648,7 +1651,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         }
         wg_fence();                                        // record and lists are in the slot before the ring says so
         if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_STASH);
-        advance();
+        adv = true;
     }
 
     __syncthreads();
