@@ -54,6 +54,9 @@ namespace RVAR {
 #ifndef LSD_REGION_NS
 #define LSD_REGION_NS 16
 #endif
+#ifndef LSD_REGION_WAIT_SLEEP
+#define LSD_REGION_WAIT_SLEEP 127      // x 64 clocks
+#endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
@@ -1472,7 +1475,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 }
                 if (!took) {
                     if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
-                    if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(8);   // nothing moved: every slot waits for the cursor, or nothing is left to hand out
+                    // nothing moved: every slot waits for the cursor, or nothing is left to hand out.  Sleep long enough that the
+                    // polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
+                    if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
                     adv = true;                            // (look at the cursor again before asking for a job)
                     LT(ST_WAIT);
                     continue;
