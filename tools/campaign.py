@@ -15,12 +15,13 @@ only = [int(x) for x in sys.argv[2:]]                      # optional: just thes
 
 
 def synth(rng):
-    rows, cols = int(rng.integers(60, 900)), int(rng.integers(60, 1200))
+    big = os.environ.get("CAMPAIGN_BIG")                                  # larger maps (spill paths, long lists): CAMPAIGN_BIG=1
+    rows, cols = (int(rng.integers(1500, 3500)), int(rng.integers(1500, 3500))) if big else (int(rng.integers(60, 900)), int(rng.integers(60, 1200)))
     m = np.zeros((rows, cols), np.uint8)
     m[rng.random((rows, cols)) < rng.uniform(0.0, 0.5)] = 255
-    for _ in range(int(rng.integers(3, 40))):
+    for _ in range(int(rng.integers(3, 160 if os.environ.get("CAMPAIGN_BIG") else 40))):
         x0, y0 = rng.integers(2, cols - 2), rng.integers(2, rows - 2)
-        L = int(rng.integers(10, 400)); a = rng.choice([0, np.pi / 2, np.pi / 4, rng.uniform(0, np.pi)])
+        L = int(rng.integers(10, 2500 if big else 400)); a = rng.choice([0, np.pi / 2, np.pi / 4, rng.uniform(0, np.pi)])
         t = np.arange(L)
         xs = np.clip((x0 + t * np.cos(a)).astype(int), 0, cols - 1); ys = np.clip((y0 + t * np.sin(a)).astype(int), 0, rows - 1)
         m[ys, xs] = 1
