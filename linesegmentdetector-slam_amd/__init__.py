@@ -308,11 +308,11 @@ class Context:
         if what == DBG_STATS:
             v = get(what, np.int64, 32)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                             "rrr_oob_reads", "cycles_rrr", "cycles_total", "cycles_grow", "cycles_rect",
-                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "resweep_batches",
-                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_idle", "cycles_select", "cycles_commit",
-                             "filter_skips"),
+                             "rrr_oob_reads", "cycles_refill", "cycles_total", "cycles_grow", "cycles_rect",
+                             "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
+                             "wait_ring", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
+                             "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
+                             "wait_noseed"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)

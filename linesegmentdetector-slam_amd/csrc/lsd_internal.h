@@ -47,6 +47,7 @@ struct Buffers {
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
     uint32_t* pw;          // n x npx : packed pixel word (see above)
     uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3 (never initialised, read only behind code 3)
+    uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
@@ -59,6 +60,7 @@ struct Buffers {
     int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
     uint32_t* order;       // n : image indices, heaviest (largest nb) first: the region stage's workgroup -> image map
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
+    uint32_t* seedpos;     // n x npx : their pixels (y*w+x), same order
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
     uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())

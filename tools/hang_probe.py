@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Developer probe: repeats a batch and reports images the region stage's watchdog gave up on (counts == -1) with the state it
+recorded; also checks that the line records are identical from run to run.   tools/hang_probe.py [n] [size] [reps] [waves]"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, torch
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+a = [int(x) for x in sys.argv[1:]]
+n, size, reps, waves = (a + [48, 1024, 5, 0][len(a):])[:4]
+maps = bench.load_maps(); ctx = lsd.Context(0); ctx.set_region_waves(waves)
+d = torch.from_numpy(bench.make_batch(maps, n, size)).cuda()
+lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+wh = lsd.scaled_size(size, size)
+ref = None
+for rep in range(reps):
+    lines.zero_()
+    t0 = time.perf_counter()
+    ctx.enqueue_device(d.data_ptr(), n, size, size, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = counts.cpu().numpy()
+    bad = np.nonzero(c < 0)[0]
+    print("rep", rep, "%.1f ms" % (dt * 1e3), "region %.1f" % ctx.timings()["region"], "lines", int(c[c > 0].sum()), "aborted", bad.tolist(), flush=True)
+    for i in bad[:4]:
+        st = ctx.fetch(int(i), lsd.DBG_STATS, wh)
+        v = list(st.values())
+        print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[24:32])), flush=True)
+    cur = (c.tobytes(), lines.cpu().numpy().tobytes())
+    if ref is None: ref = cur
+    elif cur != ref: print("   DIFFERS from run 0", flush=True)
