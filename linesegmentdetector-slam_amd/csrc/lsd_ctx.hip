@@ -34,7 +34,7 @@ struct lsd_ctx {
     double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
     double2* sc = nullptr;
     uint32_t* order = nullptr;
-    uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr, *seedpos = nullptr, *tepoch = nullptr;
+    uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr, *seedpos = nullptr, *tepoch = nullptr, *stamp8 = nullptr, *glists = nullptr;
     uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number (a wave that uses up its 2^20 clears its stamps)
     uint32_t* slist = nullptr;
     double* pend = nullptr;
@@ -42,6 +42,7 @@ struct lsd_ctx {
     int* rnum = nullptr;
     int mcap = 16384;
     int gcap = 8192;
+    int glcap = 4096;                  // entries of a list buffer of the group grower (a longer region is grown by grow())
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
@@ -221,13 +222,16 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
         HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
+        HIPCHK(c, re_alloc(&c->stamp8, ws * ((pp + 3) / 4)));
+        HIPCHK(c, hipMemset(c->stamp8, 0, ws * ((pp + 3) / 4) * sizeof(uint32_t)));   // (every region clears its own bits again)
         c->run_id = 0;
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->pend, gs * 24));
+        HIPCHK(c, re_alloc(&c->glists, ws * (size_t)region_gbufs() * (size_t)c->glcap));
         HIPCHK(c, re_alloc(&c->order, nn));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
+        HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp; c->cap_gpx = gg; c->cap_ws = ws;
@@ -254,7 +258,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int ma
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
+                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->stamp8, (void**)&c->glists, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
@@ -324,7 +328,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->stamp8, c->glists, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -394,7 +398,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
-    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
+    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch; b.stamp8 = c->stamp8; b.glists = c->glists; b.glcap = c->glcap;
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
@@ -420,7 +424,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * c->cap_npx * sizeof(uint32_t), s));
             c->run_id = 1;
         }
-        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
+        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));
         HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), s));
         // 8 wavefronts per image take a whole CU each: worth it while the batch leaves CUs idle (<= one image per CU)
         const bool wide = waves_for(c, n) == 8;
@@ -612,7 +616,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * 32; need = 256; break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * kStatWords; need = 8 * kStatWords; break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

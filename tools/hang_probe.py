@@ -25,7 +25,7 @@ for rep in range(reps):
     for i in bad[:4]:
         st = ctx.fetch(int(i), lsd.DBG_STATS, wh)
         v = list(st.values())
-        print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[24:32])), flush=True)
+        print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[40:48])), flush=True)
     cur = (c.tobytes(), lines.cpu().numpy().tobytes())
     if ref is None: ref = cur
     elif cur != ref: print("   DIFFERS from run 0", flush=True)
