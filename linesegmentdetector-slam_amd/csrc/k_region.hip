@@ -1259,31 +1259,23 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 //            relative to the seed; whoever advances the cursor checks that no line accepted since the snapshot touches it
 //   R_LIGHTL a full evaluation without marks (small region :228 or refine failed :237): aux = result slot (box and list
 //            sizes in the slot table, the lists in the slot); checked like R_LIGHT, by the pixels themselves if the box is hit
-//   R_BIG    the small-region grower gave the seed up (its region reaches regThre pixels, leaves the seed's window, or a
-//            test was too close to call): waits for a full evaluation by any wave
-//   R_GROWN  like R_BIG, but the group grower has grown the region (>= regThre pixels) to its fixpoint: aux = list buffer;
+//   R_BIG    the region has reached SCAP pixels in a group fed from the hand-out, far ahead of the cursor: waits to be grown
+//            to its fixpoint by a group once it is within kClaim seeds of the cursor (R_GROW meanwhile)
+//   R_FULL   waits for a full evaluation that grows the region itself (grow()): a list too long for a list buffer, no buffer
+//            free, or a tolerance the group grower is not made for
+//   R_GROWN  a group has grown the region (>= regThre pixels) to its fixpoint: aux = list buffer; waits for a full evaluation;
 //            the full evaluation adopts the list instead of growing it again
 //   R_EVAL   being evaluated in full, ahead of the cursor
 //   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (aux);
 //            whoever moves the cursor over it validates and commits it
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
 //   R_BUSY   being evaluated at the cursor
-enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8, R_GROWN = 9 };
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8, R_GROWN = 9, R_GROW = 10, R_FULL = 11 };
 constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
 constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
-#ifndef LSD_REGION_SOFT
-#define LSD_REGION_SOFT (64 * NW)
-#endif
-#ifndef LSD_REGION_CLAIM
-#define LSD_REGION_CLAIM (48 * NW)
-#endif
-constexpr int kClaim = LSD_REGION_CLAIM;   // how far ahead of the cursor a full evaluation may be started
-constexpr int kSoft = LSD_REGION_SOFT;     // run-ahead of the hand-out while seeds are waiting for a full evaluation
+
 constexpr int SCAP = 16;                  // list entries a group keeps in LDS (the latest ones)
 constexpr int GB = 16;                    // list buffers per wave (one per group + those waiting for their full evaluation)
-#ifndef LSD_REGION_FEED
-#define LSD_REGION_FEED 3                 // idle groups that make a wave fetch the windows of its next seeds (a memory round trip)
-#endif
 
 struct Ring {
     alignas(4) uint8_t state[RW];
@@ -1314,7 +1306,7 @@ __device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
 __device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
-    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_abort;
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_ngrow, s_abort;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
     __shared__ SlotTab stab;
@@ -1374,7 +1366,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; s_nbig = 0; s_abort = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; s_nbig = 0; s_ngrow = 0; s_abort = 0; }
         wg_fence();
     }
     __syncthreads();
@@ -1628,6 +1620,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     const int kk8 = kq + (kq >= 4);                         // 3x3 neighbourhood, row-major, centre skipped (:533-534)
     const int ox = kk8 % 3 - 1, oy = kk8 / 3 - 1;
     const bool guse = g.degThre < 1.5;                      // (the circular-distance form of the test, as in grow())
+    // schedule parameters (lsd_ctx: defaults, LSD_REGION_* environment variables for experiments)
+    const int kSoft = min(max(b.tun_soft, CH), RW), kClaim = min(max(b.tun_claim, 1), RW), kFeed = min(max(b.tun_feed, 1), 8);
+    const bool grow_big = b.tun_big != 0;                   // R_BIG seeds are grown by the groups near the cursor (else by grow() in their full evaluation)
     const float cos_tol_s = (float)g_tol0[2];
     uint32_t* const mb32 = &g_lst[wave][0];                 // member bytes of the cached pixels (NT * 64), bit g: group g's region
     const uint8_t* const mbp = reinterpret_cast<const uint8_t*>(mb32);
@@ -1640,6 +1635,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     int gn = 0, gi = 0, gex = 0, gsx = 0, gsy = 0, gsnap = 0;
     double gC = 0.0, gS = 0.0;                              // estimated sum vector of the group's region (fp64 sums of the fp32 unit vectors)
     int gbi = grp;                                          // the group's list buffer (of this wave's GB)
+    bool gbig = false;                                      // grown to the fixpoint (a seed claimed near the cursor); else up to SCAP pixels
     uint32_t* const gbuf0 = b.glists + (img * NW + wave) * (size_t)GB * b.glcap;
     const int glcap = b.glcap;
     int gxu = 0;                                            // exact angle sums of the group's region, caught up lazily in list order (:545-546)
@@ -1742,58 +1738,98 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const int nidle = 8 - __builtin_popcountll(actm & 0x0101010101010101ull);
         bool progress = false;
         int f = 0;
-        if (nidle >= (actm ? LSD_REGION_FEED : 1)) {
-            // ---- feed the idle groups.  Between chunks (the seeds of a chunk are nobody else's) a wave first looks for a full
-            //      evaluation to claim; it starts it when the groups still at work have finished ----
+        if (nidle >= (actm ? kFeed : 1)) {
+            // ---- feed the idle groups ----
+            // Seeds come from two places.  (1) The wave's chunk of the hand-out, which runs up to kSoft seeds ahead of the cursor:
+            // these regions are grown up to SCAP pixels only -- nine in ten end below regThre and are done (R_LIGHT), the others
+            // wait as R_BIG.  (2) R_BIG seeds within kClaim seeds of the cursor, oldest first: grown to their fixpoint (the further
+            // ahead a region is grown, the likelier a line accepted before its turn makes the work void), then handed to a full
+            // evaluation with their list (R_GROWN).  Between chunks a wave whose groups grow nothing long also looks for a full
+            // evaluation to claim; it starts it when the groups still at work have finished.
             f = lds_ld(&s_commit);
+            unsigned long long src_pend = 0ull;             // lanes holding a seed for an idle group: (src_k, src_pp, src_sx, src_sy)
+            int src_k = 0, src_sx = 0, src_sy = 0;
+            uint32_t src_pp = 0u;
+            bool src_big = false;
+            const bool growing_big = ballot64((gk >= 0) & gbig) != 0ull;
             if (!ch_pend && pend_k < 0) {
-                const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
-                if (stf == R_REDO || stf == R_BIG || stf == R_GROWN) {
-                    // the record at the cursor: evaluated where everything earlier is committed, no result slot needed
-                    int won = 0;
-                    if (lane == 0) {
-                        won = st_cas(rg.state, f & (RW - 1), stf, R_BUSY) ? 1 : 0;
-                        if (won && stf != R_REDO) atomicSub(&s_nbig, 1);
+                if (!growing_big) {
+                    const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
+                    if (stf == R_REDO || stf == R_BIG || stf == R_FULL || stf == R_GROWN) {
+                        // the record at the cursor: evaluated where everything earlier is committed, no result slot needed
+                        int won = 0;
+                        if (lane == 0) {
+                            won = st_cas(rg.state, f & (RW - 1), stf, R_BUSY) ? 1 : 0;
+                            if (won && (stf == R_FULL || stf == R_GROWN)) atomicSub(&s_nbig, 1);
+                            if (won && stf == R_BIG) atomicSub(&s_ngrow, 1);
+                        }
+                        won = __builtin_amdgcn_readfirstlane(won);
+                        if (won) { pend_k = f; pend_spec = false; pend_grown = stf == R_GROWN; }
                     }
-                    won = __builtin_amdgcn_readfirstlane(won);
-                    if (won) { pend_k = f; pend_spec = false; pend_grown = stf == R_GROWN; }
+                    const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
+                    if (pend_k < 0 && freem != 0ull && lds_ld(&s_nbig) > 0) {
+                        // the oldest seed waiting for a full evaluation: four records per lane and step
+                        const int lim = min(min(lds_ld(&s_next), nseeds), f + kClaim);
+                        int kb = -1;
+                        for (int base = f & ~3; base < lim && kb < 0; base += 256) {
+                            const int i0 = base + 4 * lane;
+                            uint32_t x = i0 < lim ? __hip_atomic_load(reinterpret_cast<uint32_t*>(rg.state) + ((i0 & (RW - 1)) >> 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                            int first = -1;
+                            #pragma unroll
+                            for (int t = 3; t >= 0; t--)
+                                if ((((x >> (8 * t)) & 0xffu) == (uint32_t)R_FULL || ((x >> (8 * t)) & 0xffu) == (uint32_t)R_GROWN) && i0 + t >= f && i0 + t < lim) first = i0 + t;
+                            const unsigned long long bm = ballot64(first >= 0);
+                            if (bm) kb = __builtin_amdgcn_readlane(first, __builtin_ctzll(bm));
+                        }
+                        int won = 0;
+                        if (lane == 0 && kb >= 0) {
+                            const int tgt = kb == lds_ld(&s_commit) ? R_BUSY : R_EVAL;
+                            const int was = st_ld(&rg.state[kb & (RW - 1)]);
+                            if (was == R_FULL || was == R_GROWN) won = st_cas(rg.state, kb & (RW - 1), was, tgt) ? (tgt == R_BUSY ? 2 : 1) | (was == R_GROWN ? 4 : 0) : 0;
+                            if (won) atomicSub(&s_nbig, 1);
+                        }
+                        won = __builtin_amdgcn_readfirstlane(won);
+                        if (won) {
+                            pend_k = kb; pend_spec = (won & 3) == 1; pend_grown = (won & 4) != 0; pend_slot = __builtin_ctzll(freem);
+                            if (pend_spec && lane == pend_slot) slot_k_l = kb;      // the slot is taken until the cursor has passed seed kb
+                            progress = true;
+                        }
+                    }
                 }
-                const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
-                if (pend_k < 0 && freem != 0ull && lds_ld(&s_nbig) > 0) {
-                    // the oldest seed waiting for a full evaluation: four records per lane and step
-                    // (within kClaim seeds of the cursor: a result computed further ahead is too often void at its turn)
+                if (pend_k < 0 && grow_big && lds_ld(&s_ngrow) > 0 && lds_ld(&s_nbig) <= 0) {
+                    // R_BIG seeds near the cursor for the idle groups (one record per lane and step, the oldest ones)
                     const int lim = min(min(lds_ld(&s_next), nseeds), f + kClaim);
-                    int kb = -1;
-                    for (int base = f & ~3; base < lim && kb < 0; base += 256) {
-                        const int i0 = base + 4 * lane;
-                        uint32_t x = i0 < lim ? __hip_atomic_load(reinterpret_cast<uint32_t*>(rg.state) + ((i0 & (RW - 1)) >> 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-                        int first = -1;
-                        #pragma unroll
-                        for (int t = 3; t >= 0; t--)
-                            if ((((x >> (8 * t)) & 0xffu) == (uint32_t)R_BIG || ((x >> (8 * t)) & 0xffu) == (uint32_t)R_GROWN) && i0 + t >= f && i0 + t < lim) first = i0 + t;
-                        const unsigned long long bm = ballot64(first >= 0);
-                        if (bm) kb = __builtin_amdgcn_readlane(first, __builtin_ctzll(bm));
+                    int want = nidle;
+                    for (int base = f; base < lim && want > 0; base += 64) {
+                        const int idx = base + lane;
+                        const bool isb = idx < lim && st_ld(&rg.state[idx & (RW - 1)]) == R_BIG;
+                        unsigned long long bm = ballot64(isb);
+                        while (bm && want > 0) {
+                            const int l = __builtin_ctzll(bm);
+                            bm &= bm - 1ull;
+                            int won = 0;
+                            if (lane == 0) won = st_cas(rg.state, (base + l) & (RW - 1), R_BIG, R_GROW) ? 1 : 0;
+                            won = __builtin_amdgcn_readfirstlane(won);
+                            if (won) {
+                                const int slotl = __builtin_popcountll(src_pend);
+                                if (lane == slotl) src_k = base + l;
+                                src_pend |= 1ull << slotl;
+                                want--;
+                            }
+                        }
                     }
-                    int won = 0;
-                    if (lane == 0 && kb >= 0) {
-                        const int tgt = kb == lds_ld(&s_commit) ? R_BUSY : R_EVAL;
-                        const int was = st_ld(&rg.state[kb & (RW - 1)]);
-                        if (was == R_BIG || was == R_GROWN) won = st_cas(rg.state, kb & (RW - 1), was, tgt) ? (tgt == R_BUSY ? 2 : 1) | (was == R_GROWN ? 4 : 0) : 0;
-                        if (won) atomicSub(&s_nbig, 1);
-                    }
-                    won = __builtin_amdgcn_readfirstlane(won);
-                    if (won) {
-                        pend_k = kb; pend_spec = (won & 3) == 1; pend_grown = (won & 4) != 0; pend_slot = __builtin_ctzll(freem);
-                        if (pend_spec && lane == pend_slot) slot_k_l = kb;      // the slot is taken until the cursor has passed seed kb
-                        progress = true;
+                    if (src_pend) {
+                        const int ncl = __builtin_popcountll(src_pend);
+                        if (lane == 0) atomicSub(&s_ngrow, ncl);
+                        if (lane < ncl) src_pp = seedpos[src_k];
+                        src_sx = (int)(src_pp % (uint32_t)w); src_sy = (int)(src_pp / (uint32_t)w);
+                        src_big = true;
                     }
                 }
-                if (pend_k < 0) {
+                if (pend_k < 0 && !src_pend) {
                     // reserve the next chunk of seeds
                     const int old = lds_ld(&s_next);
-                    // (beyond kSoft seeds ahead of the cursor only while no seed is waiting for a full evaluation: the further ahead a
-                    //  region is grown, the likelier a line accepted before its turn makes the work void)
-                    if (old < nseeds && old + CH - f <= (lds_ld(&s_nbig) > 0 ? kSoft : RW)) {
+                    if (old < nseeds && old + CH - f <= kSoft) {
                         int got = 0;
                         if (lane == 0) got = atomicCAS(&s_next, old, old + CH) == old ? 1 : 0;
                         got = __builtin_amdgcn_readfirstlane(got);
@@ -1810,7 +1846,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                             if (used) st_st(&rg.state[kx & (RW - 1)], R_SKIP);
                             if (!guse) {
                                 // a tolerance the group grower is not made for: every seed goes to a full evaluation
-                                if (valid && !used) st_st(&rg.state[kx & (RW - 1)], R_BIG);
+                                if (valid && !used) st_st(&rg.state[kx & (RW - 1)], R_FULL);
                                 const int nbg = __builtin_popcountll(ballot64(valid && !used));
                                 if (lane == 0 && nbg) atomicAdd(&s_nbig, nbg);
                             } else ch_pend = ballot64(valid && !used);
@@ -1819,23 +1855,26 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     }
                 }
             }
-            // idle groups take the next seeds of the chunk
+            if (!src_pend && ch_pend) { src_pend = ch_pend; src_k = ch_k0 + lane; src_pp = ch_pp; src_sx = ch_sx; src_sy = ch_sy; }
+            // idle groups take the seeds
             const unsigned long long idle0 = ~actm & 0x0101010101010101ull;     // bit 8g: group g is idle
-            if (ch_pend && idle0) {
+            if (src_pend && idle0) {
                 unsigned long long idle = idle0;
                 const int snap = lds_ld(&s_epoch);         // before anything of usedMap is read for these seeds
                 wg_fence();
                 bool ld = false;
                 uint32_t gpp = 0u;
-                while (idle && ch_pend) {
-                    const int j = __builtin_ctzll(ch_pend);
-                    ch_pend &= ch_pend - 1ull;
+                while (idle && src_pend) {
+                    const int j = __builtin_ctzll(src_pend);
+                    src_pend &= src_pend - 1ull;
                     const int gg = __builtin_ctzll(idle) >> 3;
                     idle &= idle - 1ull;
-                    const int sxj = __builtin_amdgcn_readlane(ch_sx, j), syj = __builtin_amdgcn_readlane(ch_sy, j);
-                    const uint32_t ppj = (uint32_t)__builtin_amdgcn_readlane((int)ch_pp, j);
-                    if (grp == gg) { gk = ch_k0 + j; gsx = sxj; gsy = syj; gpp = ppj; ld = true; }
+                    const int sxj = __builtin_amdgcn_readlane(src_sx, j), syj = __builtin_amdgcn_readlane(src_sy, j);
+                    const int kj = __builtin_amdgcn_readlane(src_k, j);
+                    const uint32_t ppj = (uint32_t)__builtin_amdgcn_readlane((int)src_pp, j);
+                    if (grp == gg) { gk = kj; gsx = sxj; gsy = syj; gpp = ppj; gbig = src_big; ld = true; }
                 }
+                if (!src_big) ch_pend = src_pend;          // (what is left of the chunk; claimed R_BIG seeds never outnumber the idle groups)
                 if (!tw_small) {                           // the cache held grow()'s tiles (other word format, no member bytes)
                     if (lane < NT) g_ttag[wave][lane] = -1;
                     tw_small = true;
@@ -1954,7 +1993,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 }
                 gC += acc ? (double)cl : 0.0; gS += acc ? (double)sl : 0.0;  // :545-546 (estimate)
                 gn += acc ? 1 : 0;
-                bail = bail | (acc & (gn >= glcap));                          // the buffer is full: a full evaluation grows it again
+                bail = bail | (acc & (gn >= (gbig ? glcap : SCAP)));          // far ahead of the cursor: SCAP pixels; the buffer is full
                 todo = todo & has & !bail & (kq > l);
                 if (ballot64(acc)) gdirty = true;
             }
@@ -2013,12 +2052,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         rg.aux[r] = (uint32_t)(wave * GB + gbi);
                         s_gn[wave * GB + gbi] = gn;
                     }
-                    st_st(&rg.state[r], light ? R_LIGHT : (grown ? R_GROWN : R_BIG));
+                    st_st(&rg.state[r], light ? R_LIGHT : (grown ? R_GROWN : ((gbig | !grow_big) ? R_FULL : R_BIG)));
                 }
                 if (grown) gbi = nbuf;
                 const unsigned long long lightm = ballot64(light & (kq == 0));
                 const int nbg = __builtin_popcountll(finm & ~lightm);
-                if (lane == 0 && nbg) atomicAdd(&s_nbig, nbg);
+                const int ngr = grow_big ? __builtin_popcountll(ballot64(fin & !light & !grown & !gbig & (kq == 0))) : 0;   // R_BIG: to be grown near the cursor
+                if (lane == 0 && nbg - ngr) atomicAdd(&s_nbig, nbg - ngr);
+                if (lane == 0 && ngr) atomicAdd(&s_ngrow, ngr);
                 int gsum = 0;
                 for (unsigned long long t = lightm; t; t &= t - 1ull) gsum += __builtin_amdgcn_readlane(gn, __builtin_ctzll(t));
                 STAT(ST_GROW, __builtin_popcountll(lightm)); STAT(ST_GROWN, gsum); DSTAT(ST_SMALLBAIL, nbg);
@@ -2042,11 +2083,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             // is given up after seconds of nobody moving instead of hanging the device: counts[img] = -1, the state goes to stats.
             if (lds_ld(&s_commit) != f) nwait = 0;
             if (++nwait > LSD_REGION_WATCHDOG || lds_ld(&s_abort)) {
-                if (!lds_ld(&s_abort) && b.stats && lane == 0) {
+                if (b.stats && lane == 0) {
                     long long* st = b.stats + img * kStatWords;
-                    const int fc = lds_ld(&s_commit);
-                    st[40] = fc; st[41] = lds_ld(&s_next); st[42] = nseeds; st[43] = fc < nseeds ? st_ld(&rg.state[fc & (RW - 1)]) : -1;
-                    st[44] = lds_ld(&s_nbig); st[45] = lds_ld(&s_lock); st[46] = pend_k; st[47] = wave;
+                    if (!lds_ld(&s_abort)) {
+                        const int fc = lds_ld(&s_commit);
+                        st[40] = fc; st[41] = lds_ld(&s_next); st[42] = nseeds; st[43] = fc < nseeds ? st_ld(&rg.state[fc & (RW - 1)]) : -1;
+                        st[44] = lds_ld(&s_nbig); st[45] = lds_ld(&s_lock); st[46] = pend_k; st[47] = wave;
+                    }
+                    // what this wave holds (developer record)
+                    st[24 + 2 * wave] = (long long)ch_k0 | ((long long)(pend_k + 1) << 32);
+                    st[25 + 2 * wave] = (long long)ch_pend;
                 }
                 if (lane == 0) lds_st(&s_abort, 1);
                 break;

@@ -21,6 +21,7 @@ struct lsd_ctx {
     int device = 0;
     int num_cus = 256;                 // compute units of the device
     uint32_t id_budget = 0xFFFF0u;     // curMap stamp ids a wave may use per run before it clears its stamps (lsd_debug_set_stamp_budget)
+    int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: per-variant default), see k_region.hip
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     hipStream_t stream = nullptr;      // the context's own stream
     hipStream_t last_stream = nullptr; // stream of the last enqueue
@@ -320,6 +321,13 @@ int lsd_create(lsd_ctx** out, int device) {
         if (hipHostMalloc((void**)&c->pin[k], kPinBytes, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_NOMEM; }
     c->last_stream = c->stream;
+    {   // experiments: LSD_REGION_SOFT / _CLAIM / _FEED / _BIG override the schedule of the region stage
+        const char* e;
+        if ((e = getenv("LSD_REGION_SOFT"))) c->tun_soft = atoi(e);
+        if ((e = getenv("LSD_REGION_CLAIM"))) c->tun_claim = atoi(e);
+        if ((e = getenv("LSD_REGION_FEED"))) c->tun_feed = atoi(e);
+        if ((e = getenv("LSD_REGION_BIG"))) c->tun_big = atoi(e);
+    }
     *out = c;
     return LSD_OK;
 }
@@ -402,6 +410,12 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
+    {
+        const int nw = waves_for(c, n);
+        b.tun_soft = c->tun_soft > 0 ? c->tun_soft : 64 * nw;      // seeds the hand-out runs ahead of the cursor
+        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 48 * nw;   // how far ahead of the cursor a full evaluation may start
+        b.tun_feed = c->tun_feed; b.tun_big = c->tun_big;
+    }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
 

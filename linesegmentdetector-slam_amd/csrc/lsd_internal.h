@@ -68,6 +68,7 @@ struct Buffers {
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
     uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())
+    int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)

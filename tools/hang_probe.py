@@ -26,6 +26,7 @@ for rep in range(reps):
         st = ctx.fetch(int(i), lsd.DBG_STATS, wh)
         v = list(st.values())
         print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[40:48])), flush=True)
+        print("      per wave (chunk start, pend_k, ch_pend):", [(x & 0xffffffff, (x >> 32) - 1, hex(y)) for x, y in zip(v[24:40:2], v[25:40:2])], flush=True)
     cur = (c.tobytes(), lines.cpu().numpy().tobytes())
     if ref is None: ref = cur
     elif cur != ref: print("   DIFFERS from run 0", flush=True)
