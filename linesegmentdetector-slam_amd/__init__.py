@@ -312,8 +312,8 @@ class Context:
                              "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
                              "wait_ring", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
                              "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
-                             "wait_noseed", "depth_ups", "depth_downs", "depth_end", "x3", "x4", "x5",
-                             "x6", "x7", "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
+                             "wait_noseed", "g_tile_rounds", "cycles_gtiles", "g_sitouts", "g_far_loads", "g_adopted", "g_nobuf",
+                             "g_exact", "g_group_steps", "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)

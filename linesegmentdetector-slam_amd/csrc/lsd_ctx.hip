@@ -223,9 +223,8 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
         HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
-        const size_t s8 = region_gbufs() > 0 ? ws * ((pp + 3) / 4) : 0;              // (stamp bytes + list buffers: the group grower for regions of any size)
-        HIPCHK(c, re_alloc(&c->stamp8, s8));
-        if (s8) HIPCHK(c, hipMemset(c->stamp8, 0, s8 * sizeof(uint32_t)));              // (every region clears its own bits again)
+        HIPCHK(c, re_alloc(&c->stamp8, ws * ((pp + 3) / 4)));
+        HIPCHK(c, hipMemset(c->stamp8, 0, ws * ((pp + 3) / 4) * sizeof(uint32_t)));   // (every region clears its own bits again)
         c->run_id = 0;
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
@@ -413,8 +412,8 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.max_lines = max_lines;
     {
         const int nw = waves_for(c, n);
-        b.tun_soft = c->tun_soft > 0 ? c->tun_soft : 48 * nw;      // look-ahead of the region stage (seeds ahead of the cursor): where it starts ...
-        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 240 * nw;  // ... and how far it may grow on maps whose evaluations are long
+        b.tun_soft = c->tun_soft > 0 ? c->tun_soft : 64 * nw;      // seeds the hand-out runs ahead of the cursor
+        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 48 * nw;   // how far ahead of the cursor a full evaluation may start
         b.tun_feed = c->tun_feed; b.tun_big = c->tun_big;
     }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
