@@ -306,14 +306,13 @@ class Context:
         if what == DBG_ORDER_VAL:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
-            v = get(what, np.int64, 48)
+            v = get(what, np.int64, 32)
             return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                             "rrr_oob_reads", "cycles_refill", "cycles_total", "cycles_grow", "cycles_rect",
-                             "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
-                             "wait_ring", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
-                             "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
-                             "wait_noseed", "g_tile_rounds", "cycles_gtiles", "g_sitouts", "g_far_loads", "g_adopted", "g_nobuf",
-                             "g_exact", "g_group_steps", "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
+                             "rrr_oob_reads", "cycles_rrr", "cycles_total", "cycles_grow", "cycles_rect",
+                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
+                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "resweep_batches",
+                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_idle", "cycles_select", "cycles_commit",
+                             "filter_skips"),
                             [int(x) for x in v]))
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)

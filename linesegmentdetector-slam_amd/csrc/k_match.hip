@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_match(const double* __restrict__ map_cac
         while (angDiff > 180) angDiff -= 360;
         ang = angDiff;
         const double numAllPoint = n_points;
-        if (!(numValidPoint < 0.7 * numAllPoint))                             // :388-392
+        if (n_points != 0 && !(numValidPoint < 0.7 * numAllPoint))            // :248-263 (no scan points: the score stays infinite), :388-392
             score = (sumValidDist + sumMaxDist) / (numValidPoint) + 10 * (numAllPoint - numValidPoint) / numAllPoint;
     }
     double* o = out + (size_t)cidx * 4;

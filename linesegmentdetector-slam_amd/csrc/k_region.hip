@@ -57,9 +57,6 @@ namespace RVAR {
 #ifndef LSD_REGION_WAIT_SLEEP
 #define LSD_REGION_WAIT_SLEEP 127      // x 64 clocks
 #endif
-#ifndef LSD_REGION_WATCHDOG
-#define LSD_REGION_WATCHDOG 600000     // sleeps of LSD_REGION_WAIT_SLEEP x 64 clocks (~3.4 us each) with the cursor standing still
-#endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
@@ -91,7 +88,6 @@ struct RCtx {
     const double* deg;
     uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
     uint32_t* epochmap;
-    uint32_t* tep;       // per 8x8-pixel tile: epoch + 1 of the latest accepted line with a pixel in it (0: none)
     uint32_t* stamp;     // this wave's curMap stamps
     uint32_t* spill;
     uint32_t* gcopy;
@@ -104,34 +100,16 @@ struct RCtx {
     double logNT;
     const double* lgamma;
     const double* ptab;
-    // the group grower
-    uint32_t* st8;       // this wave's stamp bytes (as words)
-    uint32_t* gbuf0;     // this wave's list buffers
-    int glcap;
-    float cos_tol0;      // cosine of the global tolerance
-    double tol0;
 };
 
-enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
-       ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
-       ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_GTILES, ST_TGTILES, ST_GSIT, ST_GFAR, ST_GADOPT, ST_GNOBUF, ST_GEXACT, ST_GSTEPG, ST_COUNT };
+enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TRRR, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
+       ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
+       ST_WAIT, ST_RESWEEP, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TIDLE, ST_TSELECT, ST_TCOMMIT, ST_SKIPPED, ST_COUNT };
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
 //  coincides with a join of wave-uniform control flow makes the compiler treat the uniform loop state as divergent)
-#ifdef LSD_REGION_STATS
-constexpr int kStatSlots = ST_COUNT;
-__device__ constexpr int sslot(int i) { return i; }
-#else
-// the product build keeps the always-on counters only (LDS is the scarce resource of this kernel)
-constexpr int kStatSlots = 12;
-__device__ constexpr int sslot(int i) {
-    return i == ST_GROW ? 0 : i == ST_GROWN ? 1 : i == ST_NFA ? 2 : i == ST_RRR ? 3 : i == ST_RRRPASS ? 4 : i == ST_SENT ? 5 : i == ST_OOB ? 6 :
-           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : 11;
-}
-#endif
-#define STAT(i, v) do { g_stat[c.wave][sslot(i)] += (unsigned long long)(v); } while (0)
+#define STAT(i, v) do { g_stat[c.wave][i] += (unsigned long long)(v); } while (0)
 #ifdef LSD_REGION_STATS
 #define DSTAT(i, v) STAT(i, v)
 #define NOW() ((long long)__builtin_amdgcn_s_memtime())
@@ -144,13 +122,13 @@ __device__ constexpr int sslot(int i) {
 // as LDS (ds_ instructions) instead of through generic pointers carried in the context (flat_ instructions).
 __shared__ uint32_t g_lst[NW][LCAP];                      // region list (packed y<<16 | x), grow order
 __shared__ uint16_t g_wl[NW][2][LCAP + 2];                // sweep worklists (+ a dummy slot for predicated stores)
-__shared__ __attribute__((aligned(16))) uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
+__shared__ uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
 __shared__ int g_ttag[NW][NT];
-__shared__ unsigned long long g_stat[NW][kStatSlots];      // per-wave counters (see ST_* above); kept out of registers
+__shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
+__shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
 __shared__ RCtx g_ctx[NW];                                // the wave's context: the out-of-line stages get the wave number and read it here
                                                           // (a struct passed by value travels through scratch memory at every call)
-__shared__ int g_epoch;                                   // accept epoch of the image (number of lines accepted so far)
 __shared__ double g_tol0[3];                              // the global tolerance (degThre) with its sine and cosine: every first grow uses it
 __shared__ double g_acc[NW][32 * 4];                      // staging of the serial (bit-exact) sums: 32 list elements x up to 4 terms
 
@@ -176,11 +154,6 @@ __device__ __forceinline__ double acc32(int wave, int lane, int cnt, double S) {
 }
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// a load that does not stop at the CU's vector cache: for words other wavefronts change with ATOMICS (performed in L2, they leave a
-// stale line in the L1 behind; plain stores of the same CU do not)
-__device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
 // Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
@@ -265,6 +238,7 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
     }
     [[maybe_unused]] const long long tt0 = NOW();
     if (__builtin_amdgcn_readfirstlane(g_ws[wave].dirty)) { wg_fence(); g_ws[wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
+    DSTAT(ST_TILEFETCH, 1);
     const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[wave].cur_id);
     AS1 const uint32_t* const pw = uglobal(c.pw);
     AS1 const uint32_t* const stamp = uglobal(c.stamp);
@@ -557,6 +531,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
             }
             if (!bulk) {
                 // ---- pixel by pixel, in reference order (lane order) ----
+                DSTAT(ST_SLOW, 1);
                 unsigned long long todo = candm;
                 while (todo) {
                     int l, decided = -1;                 // 1 take, 0 reject, -1 exact test needed
@@ -702,6 +677,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         filter = filter && room;
                         nxt_cnt += room ? nskip : 0;
                         wi += nskip;
+                        DSTAT(ST_SKIPPED, nskip);
                         continue;
                     }
                     // the run of consecutive entries to test (no skipped entry in between: its check would be stale after an accept)
@@ -839,6 +815,7 @@ __device__ __noinline__ int radius_reduce(int cw_, int sx, int sy, int num, doub
     c.lane = (int)(threadIdx.x & 63u);
     [[maybe_unused]] const long long t0 = NOW();
     const int r = radius_reduce_impl(c.wave, sx, sy, num, regdeg, denThre);
+    DSTAT(ST_TRRR, NOW() - t0);
     return r;
 }
 __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num, double regdeg, double denThre) {
@@ -1006,10 +983,6 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const double k2 = (vy2 - vy3) / (vx2 - vx3);
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
     int all = 0, ali = 0;
-    // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
-    int* const s_incl = reinterpret_cast<int*>(&g_wl[c.wave][0][0]);
-    int* const s_lo = s_incl + 64;
-    int* const s_x = s_incl + 128;
     for (int cb = 0; cb < xlen; cb += 64) {
         const int i = cb + lane;
         int cntc = 0, lo = 0, xr = 0;
@@ -1033,18 +1006,19 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
         }
         const int tot = __builtin_amdgcn_readlane(inc, 63);
         if (tot == 0) continue;
-        s_incl[lane] = inc; s_lo[lane] = lo; s_x[lane] = xr;
+        g_sincl[c.wave][lane] = inc; g_slo[c.wave][lane] = lo; g_sx[c.wave][lane] = xr;
         all += tot;
+        DSTAT(ST_NFAPX, tot);
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
             bool hit = false;
             if (t < tot) {
                 int ci = 0;                                    // smallest ci with s_incl[ci] > t
                 for (int step = 32; step >= 1; step >>= 1)
-                    if (s_incl[ci + step - 1] <= t) ci += step;
-                const int ex = ci ? s_incl[ci - 1] : 0;
-                const int j = s_lo[ci] + (t - ex);
-                const double dv = c.deg[(size_t)j * xLim + s_x[ci]];
+                    if (g_sincl[c.wave][ci + step - 1] <= t) ci += step;
+                const int ex = ci ? g_sincl[c.wave][ci - 1] : 0;
+                const int j = g_slo[c.wave][ci] + (t - ex);
+                const double dv = c.deg[(size_t)j * xLim + g_sx[c.wave][ci]];
                 hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
             }
             ali += __builtin_popcountll(ballot64(hit));
@@ -1170,248 +1144,6 @@ __device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, doub
     return 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
 }
 
-// The list of a region the group grower has grown (RegionGrower's result for that seed, grow order) becomes this wave's
-// current region, as if grow() had just returned it: list in lst / spill, curMap stamps, counters.
-__device__ __noinline__ int adopt_list(int cw_, const uint32_t* src_, int n_) {
-    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
-    c.lane = (int)(threadIdx.x & 63u);
-    const int lane = c.lane, w = uni(c.w), wave = uni(c.wave), n = uni(n_);
-    AS1 uint32_t* const stamp = uglobal(c.stamp);
-    AS1 const uint32_t* const src = uglobal(src_);
-    c.w = w; c.wave = wave;
-    uint32_t id = (uint32_t)uni((int)g_ws[wave].cur_id);
-    if ((id - (uint32_t)uni((int)c.id_base)) >= (uint32_t)uni((int)c.id_budget)) {                      // the run's stamp ids are used up: start over on clean stamps
-        for (size_t q = lane; q < (size_t)w * uni(c.h); q += 64) stamp[q] = 0u;
-        wg_fence();
-        id = c.id_base;
-    }
-    id = (uint32_t)uni((int)id + 1);
-    invalidate_tiles(c);                                   // (the cache may hold member flags of this wave's last grow(), whose list is gone now)
-    if (lane == 0) {
-        WState& ws = g_ws[wave];
-        ws.cur_id = id; ws.has_copy = 0; ws.ex_upto = 0; ws.ex_sin = 0.0; ws.ex_cos = 0.0; ws.gnum = n; ws.dirty = 1;
-    }
-    for (int k2 = lane; k2 < n; k2 += 64) {
-        const uint32_t pk = src[k2];
-        lset(c, k2, pk);
-        stamp[(pk >> 16) * (uint32_t)w + (pk & 0xffffu)] = id;
-    }
-    STAT(ST_GROW, 1);
-    STAT(ST_GROWN, n);
-    return n;
-}
-__device__ __noinline__ double atan2_nl(double y, double x) { return atan2_g(y, x); }
-
-// ---------------------------------------------------------------------------------------------
-// The group grower's steps (see the seed loop for the whole story).  Lane group g = lanes 8g..8g+7 grows the region of one seed:
-// per step its next list entry x the 8 neighbours, out of the wave's tile cache (raw packed pixel words) and the member bytes
-// next to it.  The state of the eight groups comes in and goes out through *ps (group-uniform values, one copy per lane); the
-// function runs until a group has finished (gfin = 1: fixpoint reached, :525; 2: given up -- the list has reached its cap) or
-// maxsteps steps are done.  Out of line so that the loop gets registers of its own: inlined in the seed loop it spilled.
-// ---------------------------------------------------------------------------------------------
-struct GS {
-    int gk, gn, gi, gex, gsx, gsy, gsnap, gbi, gxu, ebase, gbig, gfin;
-    uint32_t ecur;
-    double gC, gS, gxs, gxc;
-};
-constexpr int SCAPC = 16;                 // list entries a group keeps in LDS (the latest ones)
-
-__device__ __noinline__ int group_run(GS* ps, int cw_, int maxsteps_) {
-    RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
-    c.lane = (int)(threadIdx.x & 63u);
-    const int lane = c.lane, w = uni(c.w), h = uni(c.h), wave = uni(c.wave), glcap = uni(c.glcap), maxsteps = uni(maxsteps_);
-    c.w = w; c.h = h; c.wave = wave;
-    const float cos_tol_s = c.cos_tol0;
-    const double tol0 = c.tol0;
-    int gk = ps->gk, gn = ps->gn, gi = ps->gi, gex = ps->gex, gxu = ps->gxu, ebase = ps->ebase, gfin = 0;
-    const int gsx = ps->gsx, gsy = ps->gsy, gsnap = ps->gsnap, gbi = ps->gbi;
-    const bool gbig = ps->gbig != 0;
-    uint32_t ecur = ps->ecur;
-    double gC = ps->gC, gS = ps->gS, gxs = ps->gxs, gxc = ps->gxc;
-    const int grp = lane >> 3, kq = lane & 7;
-    const int kk8 = kq + (kq >= 4);                         // 3x3 neighbourhood, row-major, centre skipped (:533-534)
-    const int ox = kk8 % 3 - 1, oy = kk8 / 3 - 1;
-    uint32_t* const mb32 = &g_lst[wave][0];                 // member bytes of the cached pixels (NT * 64), bit g: group g's region
-    const uint8_t* const mbp = reinterpret_cast<const uint8_t*>(mb32);
-    uint32_t* const gring = &g_lst[wave][512 + grp * SCAPC];
-    int* const gwin = reinterpret_cast<int*>(&g_wl[wave][1][0]);
-    int* const gtepo = gwin + NT;
-    AS1 uint32_t* const st8 = uglobal(c.st8);
-    AS1 const uint32_t* const pwp = uglobal(c.pw);
-    const uint32_t gbit = 1u << grp;
-    uint32_t* const gbuf = c.gbuf0 + (size_t)gbi * glcap;
-    bool gdirty = true;                                     // (stores of the caller may be in flight)
-    const int cap = gbig ? glcap : SCAPC;
-    int steps = 0;
-    while (true) {
-        const bool act = (gk >= 0) & (gfin == 0);
-        if (!ballot64(act)) break;
-        // the entry: the latest SCAPC ones are in LDS, older ones come from the buffer eight at a time
-        const bool far = act & (gn - gi > SCAPC);
-        if (ballot64(far & ((gi & ~7) != ebase))) {
-            if (gdirty) { wg_fence(); gdirty = false; }
-            DSTAT(ST_GFAR, 1);
-            if (far & ((gi & ~7) != ebase)) { ebase = gi & ~7; ecur = ebase + kq < gn ? gbuf[ebase + kq] : 0u; }
-        }
-        const uint32_t efar = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & 56) + (gi & 7)) << 2, (int)ecur);
-        const uint32_t e = far ? efar : gring[act ? (gi & (SCAPC - 1)) : 0];
-        const int nx = (int)(e & 0xffffu) + ox, ny = (int)(e >> 16) + oy;
-        const bool inb = act & ((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h);   // :536
-        const int tx = nx >> 3, ty = ny >> 3;
-        const int key = inb ? tile_key(tx, ty) : -1;
-        const int slot = tile_slot(tx, ty);
-        bool go = act;
-        // (a tile fetched before the group's snapshot may miss a ban the validation at the cursor no longer looks for)
-        unsigned long long todo_t = ballot64(inb & ((g_ttag[wave][slot] != key) | (gtepo[slot] < gsnap)));
-        if (todo_t) {
-            // Two lanes may need different tiles in one slot: every slot goes to the tile of the lowest lane that needs it, and a
-            // group with a lane that lost its slot sits this step out (the lowest running group never does).
-            bool need = inb;
-            if (lane < NT) gwin[lane] = 0x7fffffff;
-            if (need) atomicMin(&gwin[slot], lane);
-            const int wl = need ? gwin[slot] : lane;
-            const int wkey = __builtin_amdgcn_ds_bpermute(wl << 2, key);
-            const unsigned long long losem = ballot64(need & (wkey != key));
-            if (losem) {
-                go = act & (((uint32_t)(losem >> (lane & 56)) & 0xffu) == 0u);
-                DSTAT(ST_GSIT, 1);
-                need = need & go;
-                todo_t = ballot64(need & ((g_ttag[wave][slot] != key) | (gtepo[slot] < gsnap)));
-            }
-            if (todo_t) {
-                [[maybe_unused]] const long long tg0 = NOW();
-                DSTAT(ST_GTILES, 1);
-                const int key2 = need ? key : -1;
-                const int ep = lds_ld(&g_epoch);           // the tiles will hold every ban of the lines accepted before
-                wg_fence();                                // (also: earlier stamp bytes have landed before a tile is (re)read)
-                gdirty = false;
-                const int lx = lane & 7, ly = lane >> 3;
-                while (todo_t) {
-                    int T[4], S[4];
-                    int nt = 0;
-                    #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        T[j] = -1; S[j] = 0;
-                        if (todo_t) {
-                            const int l = __builtin_ctzll(todo_t);
-                            T[j] = __builtin_amdgcn_readlane(key2, l);
-                            S[j] = __builtin_amdgcn_readlane(slot, l);
-                            todo_t &= ~ballot64(key2 == T[j]);
-                            nt++;
-                        }
-                    }
-                    uint32_t vw[4], vb[4];
-                    #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        vw[j] = kPwStatic; vb[j] = 0u;                        // outside the image: banned
-                        if (j < nt) {
-                            const int x = (T[j] & 0xffff) * 8 + lx, y = (T[j] >> 16) * 8 + ly;
-                            if ((x < w) & (y < h)) {
-                                const uint32_t q = (uint32_t)(y * w + x);
-                                vw[j] = pwp[q];
-                                vb[j] = (ld_l2((const uint32_t*)&st8[q >> 2]) >> (8 * (q & 3u))) & 0xffu;
-                            }
-                        }
-                    }
-                    #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (j < nt) {
-                            g_tw[wave][S[j] * 64 + lane] = vw[j];
-                            reinterpret_cast<uint8_t*>(mb32)[S[j] * 64 + lane] = (uint8_t)vb[j];
-                            g_ttag[wave][S[j]] = T[j];             // (all lanes, same value)
-                            gtepo[S[j]] = ep;
-                        }
-                    }
-                }
-                DSTAT(ST_TGTILES, NOW() - tg0);
-            }
-        }
-        const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);
-        const uint32_t word = g_tw[wave][cell];
-        const uint32_t mbyte = mbp[cell];
-        bool bail = false;
-        bool todo = go & inb & ((word & 1u) == 0u) & ((mbyte & gbit) == 0u);        // :537 (2 is growable, Q5)
-        float sf, cf;
-        fast_sincos(__uint_as_float(word & ~3u), sf, cf);
-        while (ballot64(todo)) {
-            // all candidates still to come, against the estimate as it stands: the ones that clearly fail before the first
-            // one that does not are decided for good (nothing is accepted in between); that one is taken if it clearly passes,
-            // and decided against the correctly rounded angle of the exact sums if it is too close to call (as in grow())
-            const float Cg = (float)gC, Sg = (float)gS;
-            const float Vg = __builtin_amdgcn_sqrtf(Cg * Cg + Sg * Sg) * 1.000001f;
-            const float nr = (float)gn * inv_ub(fmaxf(Vg, 1e-3f));
-            const float ec = kEpsU * (1.0f + 2.1f * nr) + 5e-6f;
-            const float d1 = cf * Cg + sf * Sg;
-            const unsigned long long nfm = ballot64(todo & !(d1 < (cos_tol_s - ec) * Vg));
-            const unsigned long long pm = ballot64(d1 > (cos_tol_s + ec) * Vg);
-            const uint32_t byte = (uint32_t)(nfm >> (lane & 56)) & 0xffu;
-            const bool has = byte != 0u;
-            const int l = has ? __builtin_ctz(byte) : 0;
-            const int src = (lane & 56) + l;
-            bool acc = has & (((pm >> src) & 1ull) != 0ull);
-            const bool amb = has & !acc;
-            if (ballot64(amb)) {
-                // ---- the exact test (:540-543) for the groups with a candidate too close to call ----
-                DSTAT(ST_EXACT, 1);
-                if (gdirty) { wg_fence(); gdirty = false; }
-                while (ballot64(amb & (gxu < gn))) {                         // catch the exact sums up, in list order (:545-546)
-                    const bool ldx = amb & (gxu + kq < gn);
-                    double vs = 0.0, vc = 0.0;
-                    if (ldx) {
-                        const int ix = gxu + kq;
-                        const uint32_t ex = gn - ix <= SCAPC ? gring[ix & (SCAPC - 1)] : gbuf[ix];
-                        const double2 v = c.sc[(size_t)(ex >> 16) * w + (ex & 0xffffu)];
-                        vs = v.x; vc = v.y;
-                    }
-                    #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int sl2 = ((lane & 56) + j) << 2;
-                        const double tc = __hiloint2double(__builtin_amdgcn_ds_bpermute(sl2, __double2hiint(vc)), __builtin_amdgcn_ds_bpermute(sl2, __double2loint(vc)));
-                        const double ts = __hiloint2double(__builtin_amdgcn_ds_bpermute(sl2, __double2hiint(vs)), __builtin_amdgcn_ds_bpermute(sl2, __double2loint(vs)));
-                        if (amb & (gxu + j < gn)) { gxc += tc; gxs += ts; }
-                    }
-                    if (amb) gxu = min(gxu + 8, gn);
-                }
-                bool exok = false;
-                if (amb) {
-                    const double R = gn == 1 ? c.deg[(size_t)gsy * w + gsx] : atan2_nl(gxs, gxc);   // :547 (the seed's angle until the first accept)
-                    const double dq = inb ? c.deg[(size_t)ny * w + nx] : 0.0;
-                    const double dl = __hiloint2double(__builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(dq)), __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(dq)));
-                    exok = angle_diff(R, dl) < tol0;                                              // :540-543
-                }
-                acc = acc | (amb & exok);
-            }
-            const float cl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(cf)));
-            const float sl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(sf)));
-            if (acc & (kq == l)) {
-                const uint32_t q = (uint32_t)(ny * w + nx);
-                atomicOr(&mb32[cell >> 2], gbit << (8 * (cell & 3)));         // :549
-                atomicOr((uint32_t*)&st8[q >> 2], gbit << (8 * (q & 3u)));
-                gring[gn & (SCAPC - 1)] = pack_xy(nx, ny);                    // :551-556
-                gbuf[gn] = pack_xy(nx, ny);
-            }
-            gC += acc ? (double)cl : 0.0; gS += acc ? (double)sl : 0.0;      // :545-546 (estimate)
-            gn += acc ? 1 : 0;
-            bail = bail | (acc & (gn >= cap));                                // far ahead of the cursor: SCAP pixels; the buffer is full
-            todo = todo & has & !bail & (kq > l);
-            if (ballot64(acc)) gdirty = true;
-        }
-        const int ni = gi + 1;
-        const bool sweep_end = go & !bail & (ni >= gn);                       // :529 (the list is live)
-        const bool done = sweep_end & (gn == gex);                           // :525 a sweep that added nothing
-        gex = sweep_end ? gn : gex;
-        gi = sweep_end ? 0 : (go ? ni : gi);
-        gfin = act ? (bail ? 2 : (done ? 1 : 0)) : gfin;
-        steps++;
-        DSTAT(ST_SMALLSTEPS, 1);
-        DSTAT(ST_GSTEPG, __builtin_popcountll(ballot64(act & (kq == 0))));
-        if (ballot64(gfin != 0) || steps >= maxsteps) break;
-    }
-    ps->gn = gn; ps->gi = gi; ps->gex = gex; ps->gxu = gxu; ps->ebase = ebase; ps->gfin = gfin; ps->ecur = ecur;
-    ps->gC = gC; ps->gS = gS; ps->gxs = gxs; ps->gxc = gxc;
-    return steps;
-}
-
 // ---------------------------------------------------------------------------------------------
 // seed loop, myLSD.cpp:219-272
 // ---------------------------------------------------------------------------------------------
@@ -1436,7 +1168,7 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
         const size_t q = (size_t)y * w + x;
         if (src || c.stamp[q] == cur_id) {        // curMap == 1 only (src: a stashed list holds exactly those)
             const uint32_t old = c.pw[q];
-            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1); }
+            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; }
             else c.pw[q] = (old & ~3u) | kPwRejected;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
@@ -1468,68 +1200,33 @@ __device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) 
     return bx;
 }
 
+__device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Commit ring: one record per seed in flight (index = seed number & (RW-1)).
-//   R_EMPTY  reserved by a wave (part of its chunk of seeds), not classified yet
-//   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
-//   R_LIGHT  a small region (:228, nothing to mark) grown by the small-region grower: aux = box of what it examined,
-//            relative to the seed; whoever advances the cursor checks that no line accepted since the snapshot touches it
-//   R_LIGHTL a full evaluation without marks (small region :228 or refine failed :237): aux = result slot (box and list
-//            sizes in the slot table, the lists in the slot); checked like R_LIGHT, by the pixels themselves if the box is hit
-//   R_BIG    the region has reached SCAP pixels in a group fed from the hand-out, far ahead of the cursor: waits to be grown
-//            to its fixpoint by a group once it is within kClaim seeds of the cursor (R_GROW meanwhile)
-//   R_FULL   waits for a full evaluation that grows the region itself (grow()): a list too long for a list buffer, no buffer
-//            free, or a tolerance the group grower is not made for
-//   R_GROWN  a group has grown the region (>= regThre pixels) to its fixpoint: aux = list buffer; waits for a full evaluation;
-//            the full evaluation adopts the list instead of growing it again
-//   R_EVAL   being evaluated in full, ahead of the cursor
-//   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (aux);
+//   R_EMPTY  not evaluated yet
+//   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (lref);
 //            whoever moves the cursor over it validates and commits it
+//   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
+//   R_LIGHT  evaluated, no marks to make (small region :228 or refine failed :237); whoever advances the
+//            cursor checks that no line accepted since the record's snapshot touches what it examined
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
-//   R_BUSY   being evaluated at the cursor
-enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8, R_GROWN = 9, R_GROW = 10, R_FULL = 11 };
-constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
-constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
-
-constexpr int SCAP = 16;                  // list entries a group keeps in LDS (the latest ones)
-constexpr int GB = 16;                    // list buffers per wave (one per group + those waiting for their full evaluation)
+//   R_BUSY   being re-evaluated at the cursor
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5 };
+constexpr int RW = NW == 4 ? 128 : 256;   // records in flight (> NW * NS + run-ahead over skipped seeds)
 
 struct Ring {
-    alignas(4) uint8_t state[RW];
-    uint16_t snap[RW];   // accept epoch (mod 2^16) the result was computed against
-    uint32_t aux[RW];    // see above
+    int state[RW];
+    int snap[RW];
+    short box[RW][4];
+    uint32_t lref[RW];   // list slot of the region (wave * NS + slot), ~0u: no lists kept (box check only)
+    uint32_t lcnt[RW];   // n1 | n2 << 16: sizes of the two lists in the slot (first grow, Refiner's regrow)
 };
-struct SlotTab {         // per result slot (wave * NS + slot) of a full evaluation published as R_LIGHTL
-    short box[NW * NS][4];
-    uint32_t lcnt[NW * NS];   // n1 + 1 | n2 << 16 (n1 + 1 == 0: the lists were not kept, box check only)
-};
-__device__ __forceinline__ int st_ld(uint8_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void st_st(uint8_t* p, int v) { __hip_atomic_store(p, (uint8_t)v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// compare-and-swap of ONE state byte (call it from one lane): the containing word is swapped, and the swap is retried as long
-// as only the other three bytes of the word have changed in between
-__device__ __forceinline__ bool st_cas(uint8_t* base, int idx, int expect, int desired) {
-    uint32_t* const wp = reinterpret_cast<uint32_t*>(base) + (idx >> 2);
-    const int sh = (idx & 3) * 8;
-    while (true) {
-        const uint32_t oldw = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (((oldw >> sh) & 0xffu) != (uint32_t)expect) return false;
-        const uint32_t neww = (oldw & ~(0xffu << sh)) | ((uint32_t)desired << sh);
-        if (atomicCAS(wp, oldw, neww) == oldw) return true;
-    }
-}
-
-// minimum / maximum over the 8 lanes of a group for small non-negative integers (exact in fp32)
-__device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
-__device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
-    int& s_epoch = g_epoch;
-    __shared__ int s_next, s_commit, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_ngrow, s_abort;
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
-    __shared__ SlotTab stab;
-    __shared__ int s_gfree[NW];            // free list buffers of each wave (bit i: buffer i)
-    __shared__ int s_gn[NW * GB];          // size of the list in a buffer handed over with R_GROWN
 
     const size_t img = b.order[blockIdx.x];               // heaviest images first (k_order)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1539,7 +1236,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     RCtx c;
     c.w = w; c.h = h; c.lane = lane; c.wave = wave;
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
-    c.tep = b.tepoch + img * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
     c.sc = b.sc + img * npx;
     c.stamp = b.stamps + (img * NW + wave) * npx;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
@@ -1551,19 +1247,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
     }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
-    c.st8 = b.stamp8 + (img * NW + wave) * (size_t)((npx + 3) >> 2);
-    c.gbuf0 = b.glists + (img * NW + wave) * (size_t)GB * b.glcap; c.glcap = b.glcap;
-    c.cos_tol0 = 0.0f; c.tol0 = g.degThre;
     if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
-    if (lane < kStatSlots) g_stat[c.wave][lane] = 0ull;
+    if (lane < ST_COUNT) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
     if (lane < NT) g_ttag[c.wave][lane] = -1;
-    if (lane == 0) s_gfree[wave] = 0xff00;                 // (buffers 0..7 start with the groups)
-    for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
+    for (int j = threadIdx.x; j < RW; j += 64 * NW) rg.state[j] = R_EMPTY;
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
-    uint32_t* seedpos = b.seedpos + img * npx;
     const int nb = b.nb[img];
     double* recs = b.recs + img * (size_t)b.max_lines * 12;
     double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
@@ -1581,18 +1272,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int base = 0; base < nb; base += 64) {
             const int idx = base + lane;
-            const uint32_t pq = ord[idx < nb ? idx : 0];
-            const bool ok = idx < nb && (c.pw[pq] & 3u) == 0u;   // :222
+            const bool ok = idx < nb && (c.pw[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
             const unsigned long long m = ballot64(ok);
-            if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
+            if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; s_nbig = 0; s_ngrow = 0; s_abort = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; }
         wg_fence();
     }
     __syncthreads();
     const int nseeds = s_nseeds;
-    if (lane == 0) g_ctx[wave].cos_tol0 = (float)g_tol0[2];
 
     // box overlap of record-style boxes against the lines accepted in epochs [snap, now)
     auto hit_since = [&](int snap, int now, int x0, int y0, int x1, int y1) -> bool {
@@ -1608,7 +1297,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (lane == 0) {
             if (trace) {
                 const int oidx = (int)seedidx[k];
-                const uint32_t pp = seedpos[k];
+                const uint32_t pp = ord[oidx];
                 SeedRec tr;
                 tr.order_idx = oidx; tr.x = (int)(pp % (uint32_t)w); tr.y = (int)(pp / (uint32_t)w);
                 tr.num = num0; tr.outcome = outcome; tr.final_num = fnum; tr.logNFA = logNFA;
@@ -1621,20 +1310,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     // >= snap: only then can the region's evaluation differ from what it would be now (it read usedMap only as
     // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 in epochmap.
     auto examined_hit = [&](const uint32_t* lp, int cnt, int snap) -> bool {
-        // first by tiles (tep[] is a few KB and stays in the cache): no line accepted since the snapshot has a pixel in any tile
-        // the region's pixels or their neighbours lie in -> nothing examined can have been banned
-        const int tX = c.tilesX;
-        bool thit = false;
-        for (int base = 0; base < cnt; base += 64) {
-            const int k2 = base + lane;
-            if (k2 < cnt) {
-                const uint32_t pkx = lp[k2];
-                const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
-                const int xa = max(x - 1, 0) >> 3, xb = min(x + 1, w - 1) >> 3, ya = max(y - 1, 0) >> 3, yb = min(y + 1, h - 1) >> 3;
-                if ((int)ld_l2(&c.tep[ya * tX + xa]) > snap || (int)ld_l2(&c.tep[ya * tX + xb]) > snap || (int)ld_l2(&c.tep[yb * tX + xa]) > snap || (int)ld_l2(&c.tep[yb * tX + xb]) > snap) thit = true;
-            }
-        }
-        if (!ballot64(thit)) return false;
         bool hit = false;
         for (int base = 0; base < cnt; base += 64) {
             const int k2 = base + lane;
@@ -1652,16 +1327,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
         }
         return ballot64(hit) != 0ull;
-    };
-    // the same question for a box: true if a tile overlapping it holds a pixel of a line accepted in epoch >= snap
-    auto box_tile_hit = [&](int snap, int x0, int y0, int x1, int y1) -> bool {
-        const int tX = c.tilesX;
-        const int xa = max(x0, 0) >> 3, xb = min(x1, w - 1) >> 3, ya = max(y0, 0) >> 3, yb = min(y1, h - 1) >> 3;
-        bool hit = false;
-        for (int ty = ya; ty <= yb; ty++)
-            for (int tx = xa; tx <= xb; tx++)
-                if ((int)ld_l2(&c.tep[ty * tX + tx]) > snap) hit = true;
-        return hit;
     };
     // Commits a result that marks usedMap (accepted line: code 3 + epoch; rejected region: code 2), at the cursor, under
     // the cursor lock: pv = lane j < 12: field j of the rectangle (structRec order); m_src: the pixels to mark (null: this
@@ -1700,87 +1365,41 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         got = __builtin_amdgcn_readfirstlane(got);
         if (!got) return;
         while (true) {
-            int f = lds_ld(&s_commit);
+            const int f = lds_ld(&s_commit);
             if (f >= nseeds) break;
-            if (!trace) {
-                // a run of up to 64 records that need nothing but the cursor's nod (skipped seeds, results without marks that no
-                // line accepted since their snapshot can have touched), one record per lane
-                const int now = lds_ld(&s_epoch);
-                const int idx = f + lane;
-                const int rr = idx & (RW - 1);
-                const int stl = idx < nseeds ? st_ld(&rg.state[rr]) : R_EMPTY;
-                const uint32_t sp = idx < nseeds ? seedpos[idx] : 0u;           // (used only when a box has to be placed)
-                bool ok = stl == R_SKIP;
-                if (stl == R_LIGHT || stl == R_LIGHTL) {
-                    const int d = (now - (int)rg.snap[rr]) & 0xffff;
-                    ok = d == 0;
-                    if (!ok) {
-                        const uint32_t ax = rg.aux[rr];
-                        int x0, y0, x1, y1;
-                        if (stl == R_LIGHT) {
-                            const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
-                            x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
-                            x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
-                        } else { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
-                        // (the tile test only for the small boxes: a full evaluation's box may span the image, its lists say more)
-                        ok = !hit_since(now - d, now, x0, y0, x1, y1) || (stl == R_LIGHT && !box_tile_hit(now - d, x0, y0, x1, y1));
-                    }
-                }
-                const unsigned long long okm = ballot64(ok);
-                const int run = okm == ~0ull ? 64 : __builtin_ctzll(~okm);
-                if (run > 0) {
-                    const unsigned long long runm = run == 64 ? ~0ull : (1ull << run) - 1ull;
-                    const int nl = __builtin_popcountll(ballot64(stl != R_SKIP) & runm);
-                    if (lane < run) rg.state[rr] = (uint8_t)R_EMPTY;
-                    if (lane == 0) { s_ntrace = s_ntrace + nl; lds_st(&s_commit, f + run); }
-                    f += run;
-                    if (run == 64 || f >= nseeds) continue;
-                }
-            }
             const int r = f & (RW - 1);
-            const int st = st_ld(&rg.state[r]);
+            const int st = lds_ld(&rg.state[r]);
             if (st == R_SKIP) {
-                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
-            if (st == R_LIGHT || st == R_LIGHTL) {
-                const int now = lds_ld(&s_epoch);
-                const int d = (now - (int)rg.snap[r]) & 0xffff, snap = now - d;
-                const uint32_t ax = rg.aux[r];
-                if (d != 0) {
-                    int x0, y0, x1, y1;
-                    if (st == R_LIGHT) {
-                        const uint32_t sp = seedpos[f];
-                        const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
-                        x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
-                        x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
-                    } else { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
-                    if (hit_since(snap, now, x0, y0, x1, y1) && (st == R_LIGHTL || box_tile_hit(snap, x0, y0, x1, y1))) {
-                        bool conflict = true;
-                        if (st == R_LIGHTL && (stab.lcnt[ax] & 0xffffu) != 0u) {   // the lists are still in their slot: look at the pixels themselves
-                            const uint32_t lc = stab.lcnt[ax];
-                            wg_fence();
-                            conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + ax) * b.gcap, (int)(lc & 0xffffu) - 1 + (int)(lc >> 16), snap);
-                        }
-                        if (conflict) {
-                            STAT(ST_REDO, 1);
-                            if (lane == 0) st_st(&rg.state[r], R_REDO);
-                            break;
-                        }
+            if (st == R_LIGHT) {
+                const int snap = rg.snap[r], now = lds_ld(&s_epoch);
+                const short* bx = rg.box[r];
+                if (now != snap && hit_since(snap, now, bx[0], bx[1], bx[2], bx[3])) {
+                    const uint32_t lr = rg.lref[r], lc = rg.lcnt[r];
+                    bool conflict = true;
+                    if (lr != ~0u) {                       // the lists are still in their slot: look at the pixels themselves
+                        wg_fence();
+                        conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
+                    }
+                    if (conflict) {
+                        if (lane == 0) lds_st(&rg.state[r], R_REDO);
+                        break;
                     }
                 }
                 bool used_now = false;
-                if (trace) used_now = (c.pw[seedpos[f]] & 3u) != 0u;          // the reference skips it then (:222): no record
+                if (trace) used_now = (c.pw[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
                 if (trace && !used_now) {
                     const int no = rnum[r * 2 + 1];
                     write_trace(f, rnum[r * 2], no >> 2, no & 3, 0.0);
                 } else if (!trace) write_trace(f, 0, 0, 0, 0.0);
-                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             if (st == R_STASH) {
                 // ---- a stashed result at the cursor: is it still what the sequential run would get? ----
-                const uint32_t lr = rg.aux[r];
+                const uint32_t lr = rg.lref[r];
                 wg_fence();
                 const double pv = b.pend[(img * (size_t)(NW * NS) + lr) * 24 + (lane < 24 ? lane : 0)];
                 const double logNFA = rl(pv, 12);
@@ -1791,9 +1410,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 const int st_n1 = (int)(pk3 % 32768ll) - 1, st_n2 = (int)((pk3 / 32768ll) % 32768ll);
                 const uint32_t* st_list = b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap;
                 const uint32_t* m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
-                if ((c.pw[seedpos[f]] & 3u) != 0u) {       // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
+                if ((c.pw[ord[seedidx[f]]] & 3u) != 0u) {  // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
                     STAT(ST_DISCARD, 1);
-                    if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
+                    if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                     continue;
                 }
                 const int now = lds_ld(&s_epoch);
@@ -1802,12 +1421,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (st_n1 >= 0) conflict = examined_hit(st_list, st_n1 + st_n2, snap);   // the pixels themselves
                     if (conflict) {
                         STAT(ST_REDO, 1);
-                        if (lane == 0) st_st(&rg.state[r], R_REDO);      // evaluate again; everything earlier is committed now
+                        if (lane == 0) lds_st(&rg.state[r], R_REDO);     // evaluate again; everything earlier is committed now
                         break;
                     }
                 }
                 commit_marks(f, num0, num, outcome, logNFA, pv, m_src, m_cnt);
-                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             break;
@@ -1820,361 +1439,62 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
     int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
+    int win_k0 = -64;                                      // window of seeds in registers (see the seed loop)
+    uint32_t win_pp = 0u;
+    unsigned long long win_used = 0ull;
     const unsigned long long ltm = (1ull << lane) - 1ull;
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
 #define LT(i) do { const long long t_ = NOW(); DSTAT((i), t_ - tl); tl = t_; } while (0)
     bool adv = false;                                      // a record has been published since the cursor was last looked at
-
-    // ---- The group grower: eight seeds side by side ----
-    // Nine seeds in ten grow a region of fewer than regThre (12..16) pixels and are dropped at once (:228), and a region is a
-    // thin wall whose frontier keeps 8..16 of the 64 lanes of grow() busy.  So the wave's eight 8-lane GROUPS each grow the region
-    // of one seed, one list entry x its 8 neighbours per step.  The neighbourhoods come from the wave's tile cache (raw packed
-    // pixel words here) shared by the eight regions, which usually sit on the same structures; membership (curMap) is bit g of
-    // a byte per cached pixel, written through to the wave's stamp bytes in HBM (st8) so that an evicted tile can come back,
-    // and cleared again pixel by pixel when the region is done.  The candidates of an entry are decided in reference order
-    // against the estimated sum vector exactly as grow() decides a batch pixel by pixel; a test too close to call, or a region
-    // that reaches regThre pixels, hands the seed over to a full evaluation (R_BIG), which starts from scratch.  A region that
-    // reaches its fixpoint first is what RegionGrower returns for that seed, decision for decision; nothing of usedMap is
-    // written, so the result is published as R_LIGHT with the box of what it examined.  Groups take the next seed of the
-    // wave's chunk as they finish.
-    const int grp = lane >> 3, kq = lane & 7;
-    const bool guse = g.degThre < 1.5;                      // (the circular-distance form of the test, as in grow())
-    // schedule parameters (lsd_ctx: defaults, LSD_REGION_* environment variables for experiments)
-    const int kSoft = min(max(b.tun_soft, CH), RW), kClaim = min(max(b.tun_claim, 1), RW), kFeed = min(max(b.tun_feed, 1), 8);
-    const bool grow_big = b.tun_big != 0;                   // R_BIG seeds are grown by the groups near the cursor (else by grow() in their full evaluation)
-    uint32_t* const mb32 = &g_lst[wave][0];                 // member bytes of the cached pixels (NT * 64), bit g: group g's region
-    uint32_t* const gring = &g_lst[wave][512 + grp * SCAP]; // this group's list: y << 16 | x
-    uint32_t* const st8 = b.stamp8 + (img * NW + wave) * (size_t)((npx + 3) >> 2);   // stamp bytes of this wave, as words
-    const uint32_t gbit = 1u << grp;
-    GS gs;                                                  // the groups' state (group_run() works on it)
-    gs.gk = -1; gs.gn = 0; gs.gi = 0; gs.gex = 0; gs.gsx = 0; gs.gsy = 0; gs.gsnap = 0; gs.gbi = grp; gs.gxu = 0; gs.ebase = -8; gs.gbig = 0; gs.gfin = 0;
-    gs.ecur = 0u; gs.gC = 0.0; gs.gS = 0.0; gs.gxs = 0.0; gs.gxc = 0.0;
-    int& gk = gs.gk;                                        // seed of this lane's group, -1: idle
-    int& gn = gs.gn; int& gi = gs.gi; int& gex = gs.gex; int& gsx = gs.gsx; int& gsy = gs.gsy; int& gsnap = gs.gsnap;
-    double& gC = gs.gC; double& gS = gs.gS;                 // estimated sum vector of the group's region (fp64 sums of the fp32 unit vectors)
-    int& gbi = gs.gbi;                                      // the group's list buffer (of this wave's GB)
-    int& gbig = gs.gbig;                                    // grown to the fixpoint (a seed claimed near the cursor); else up to SCAP pixels
-    uint32_t* const gbuf0 = b.glists + (img * NW + wave) * (size_t)GB * b.glcap;
-    const int glcap = b.glcap;
-    int& gxu = gs.gxu;                                      // exact angle sums of the group's region, caught up lazily in list order (:545-546)
-    double& gxs = gs.gxs; double& gxc = gs.gxc;
-    int& ebase = gs.ebase;                                  // list entries [ebase, ebase + 8) are in ecur (lane kq: entry ebase + kq)
-    int ch_k0 = 0, ch_sx = 0, ch_sy = 0;                    // the wave's chunk: lane j < CH holds seed ch_k0 + j
-    uint32_t ch_pp = 0u;
-    unsigned long long ch_pend = 0ull;                      // seeds of the chunk not handed to a group yet
-    bool tw_small = false;                                  // g_tw / g_lst are in the group grower's use (raw words, member bytes)
-    bool gdirty = false;                                    // stamp bytes written since the last fence
-
-    int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done
-    bool pend_spec = false, pend_grown = false;             // (pend_grown: the region has been grown, its list waits in a buffer)
-    int nwait = 0;                                          // consecutive looks that found nothing to do (watchdog)
     while (true) {
-        if (adv) {
-            // (the cursor is worth a look only when the record it stands on is finished)
-            const int f0 = lds_ld(&s_commit);
-            const int s0 = f0 < nseeds ? st_ld(&rg.state[f0 & (RW - 1)]) : R_EMPTY;
-            LT(ST_TSELECT);
-            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH) advance();
-            adv = false;
-            LT(ST_TCOMMIT);
-        }
+        // (one call site: the cursor code is inlined once, not once per kind of result)
+        if (adv) { advance(); adv = false; }
+        // ---- choose the next job ----
+        int k, slot = 0;
+        bool spec;
         LT(ST_TSELECT);
-        const unsigned long long actm = ballot64(gk >= 0);
-        const int nidle = 8 - __builtin_popcountll(actm & 0x0101010101010101ull);
-        bool progress = false;
-        int f = 0;
-        if (nidle >= (actm ? kFeed : 1)) {
-            // ---- feed the idle groups ----
-            // Seeds come from two places.  (1) The wave's chunk of the hand-out, which runs up to kSoft seeds ahead of the cursor:
-            // these regions are grown up to SCAP pixels only -- nine in ten end below regThre and are done (R_LIGHT), the others
-            // wait as R_BIG.  (2) R_BIG seeds within kClaim seeds of the cursor, oldest first: grown to their fixpoint (the further
-            // ahead a region is grown, the likelier a line accepted before its turn makes the work void), then handed to a full
-            // evaluation with their list (R_GROWN).  Between chunks a wave whose groups grow nothing long also looks for a full
-            // evaluation to claim; it starts it when the groups still at work have finished.
-            f = lds_ld(&s_commit);
-            unsigned long long src_pend = 0ull;             // lanes holding a seed for an idle group: (src_k, src_pp, src_sx, src_sy)
-            int src_k = 0, src_sx = 0, src_sy = 0;
-            uint32_t src_pp = 0u;
-            bool src_big = false;
-            const bool growing_big = ballot64((gk >= 0) & (gbig != 0)) != 0ull;
-            if (!ch_pend && pend_k < 0) {
-                if (!growing_big) {
-                    const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
-                    if (stf == R_REDO || stf == R_BIG || stf == R_FULL || stf == R_GROWN) {
-                        // the record at the cursor: evaluated where everything earlier is committed, no result slot needed
-                        int won = 0;
-                        if (lane == 0) {
-                            won = st_cas(rg.state, f & (RW - 1), stf, R_BUSY) ? 1 : 0;
-                            if (won && (stf == R_FULL || stf == R_GROWN)) atomicSub(&s_nbig, 1);
-                            if (won && stf == R_BIG) atomicSub(&s_ngrow, 1);
-                        }
-                        won = __builtin_amdgcn_readfirstlane(won);
-                        if (won) { pend_k = f; pend_spec = false; pend_grown = stf == R_GROWN; }
-                    }
-                    const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
-                    if (pend_k < 0 && freem != 0ull && lds_ld(&s_nbig) > 0) {
-                        // the oldest seed waiting for a full evaluation: four records per lane and step
-                        const int lim = min(min(lds_ld(&s_next), nseeds), f + kClaim);
-                        int kb = -1;
-                        for (int base = f & ~3; base < lim && kb < 0; base += 256) {
-                            const int i0 = base + 4 * lane;
-                            uint32_t x = i0 < lim ? __hip_atomic_load(reinterpret_cast<uint32_t*>(rg.state) + ((i0 & (RW - 1)) >> 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-                            int first = -1;
-                            #pragma unroll
-                            for (int t = 3; t >= 0; t--)
-                                if ((((x >> (8 * t)) & 0xffu) == (uint32_t)R_FULL || ((x >> (8 * t)) & 0xffu) == (uint32_t)R_GROWN) && i0 + t >= f && i0 + t < lim) first = i0 + t;
-                            const unsigned long long bm = ballot64(first >= 0);
-                            if (bm) kb = __builtin_amdgcn_readlane(first, __builtin_ctzll(bm));
-                        }
-                        int won = 0;
-                        if (lane == 0 && kb >= 0) {
-                            const int tgt = kb == lds_ld(&s_commit) ? R_BUSY : R_EVAL;
-                            const int was = st_ld(&rg.state[kb & (RW - 1)]);
-                            if (was == R_FULL || was == R_GROWN) won = st_cas(rg.state, kb & (RW - 1), was, tgt) ? (tgt == R_BUSY ? 2 : 1) | (was == R_GROWN ? 4 : 0) : 0;
-                            if (won) atomicSub(&s_nbig, 1);
-                        }
-                        won = __builtin_amdgcn_readfirstlane(won);
-                        if (won) {
-                            pend_k = kb; pend_spec = (won & 3) == 1; pend_grown = (won & 4) != 0; pend_slot = __builtin_ctzll(freem);
-                            if (pend_spec && lane == pend_slot) slot_k_l = kb;      // the slot is taken until the cursor has passed seed kb
-                            progress = true;
-                        }
-                    }
-                }
-                if (pend_k < 0 && grow_big && lds_ld(&s_ngrow) > 0 && lds_ld(&s_nbig) <= 0) {
-                    // R_BIG seeds near the cursor for the idle groups (one record per lane and step, the oldest ones)
-                    const int lim = min(min(lds_ld(&s_next), nseeds), f + kClaim);
-                    int want = nidle;
-                    for (int base = f; base < lim && want > 0; base += 64) {
-                        const int idx = base + lane;
-                        const bool isb = idx < lim && st_ld(&rg.state[idx & (RW - 1)]) == R_BIG;
-                        unsigned long long bm = ballot64(isb);
-                        while (bm && want > 0) {
-                            const int l = __builtin_ctzll(bm);
-                            bm &= bm - 1ull;
-                            int won = 0;
-                            if (lane == 0) won = st_cas(rg.state, (base + l) & (RW - 1), R_BIG, R_GROW) ? 1 : 0;
-                            won = __builtin_amdgcn_readfirstlane(won);
-                            if (won) {
-                                const int slotl = __builtin_popcountll(src_pend);
-                                if (lane == slotl) src_k = base + l;
-                                src_pend |= 1ull << slotl;
-                                want--;
-                            }
-                        }
-                    }
-                    if (src_pend) {
-                        const int ncl = __builtin_popcountll(src_pend);
-                        if (lane == 0) atomicSub(&s_ngrow, ncl);
-                        if (lane < ncl) src_pp = seedpos[src_k];
-                        src_sx = (int)(src_pp % (uint32_t)w); src_sy = (int)(src_pp / (uint32_t)w);
-                        src_big = true;
-                    }
-                }
-                if (pend_k < 0 && !src_pend) {
-                    // reserve the next chunk of seeds
-                    const int old = lds_ld(&s_next);
-                    if (old < nseeds && old + CH - f <= kSoft) {
-                        int got = 0;
-                        if (lane == 0) got = atomicCAS(&s_next, old, old + CH) == old ? 1 : 0;
-                        got = __builtin_amdgcn_readfirstlane(got);
-                        progress = true;                       // (lost the race: somebody moved, look again)
-                        if (got) {
-                            ch_k0 = old;
-                            const int kx = old + lane;
-                            const bool valid = lane < CH && kx < nseeds;
-                            uint32_t pp = 0u, code = 1u;
-                            if (valid) { pp = seedpos[kx]; code = c.pw[pp] & 3u; }
-                            ch_pp = pp;
-                            ch_sx = (int)(pp % (uint32_t)w); ch_sy = (int)(pp / (uint32_t)w);
-                            const bool used = valid && code != 0u;      // monotone: once used, always used (:222)
-                            if (used) st_st(&rg.state[kx & (RW - 1)], R_SKIP);
-                            if (!guse) {
-                                // a tolerance the group grower is not made for: every seed goes to a full evaluation
-                                if (valid && !used) st_st(&rg.state[kx & (RW - 1)], R_FULL);
-                                const int nbg = __builtin_popcountll(ballot64(valid && !used));
-                                if (lane == 0 && nbg) atomicAdd(&s_nbig, nbg);
-                            } else ch_pend = ballot64(valid && !used);
-                            adv = true;
-                        }
-                    }
-                }
+        const int f = lds_ld(&s_commit);
+        {
+            // a record waiting to be redone at the cursor has priority
+            int won = 0;
+            if (f < nseeds && lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) {
+                if (lane == 0) won = atomicCAS(&rg.state[f & (RW - 1)], R_REDO, R_BUSY) == R_REDO ? 1 : 0;
+                won = __builtin_amdgcn_readfirstlane(won);
             }
-            if (!src_pend && ch_pend) { src_pend = ch_pend; src_k = ch_k0 + lane; src_pp = ch_pp; src_sx = ch_sx; src_sy = ch_sy; }
-            // idle groups take the seeds
-            const unsigned long long idle0 = ~actm & 0x0101010101010101ull;     // bit 8g: group g is idle
-            if (src_pend && idle0) {
-                unsigned long long idle = idle0;
-                const int snap = lds_ld(&s_epoch);         // before anything of usedMap is read for these seeds
-                wg_fence();
-                bool ld = false;
-                uint32_t gpp = 0u;
-                while (idle && src_pend) {
-                    const int j = __builtin_ctzll(src_pend);
-                    src_pend &= src_pend - 1ull;
-                    const int gg = __builtin_ctzll(idle) >> 3;
-                    idle &= idle - 1ull;
-                    const int sxj = __builtin_amdgcn_readlane(src_sx, j), syj = __builtin_amdgcn_readlane(src_sy, j);
-                    const int kj = __builtin_amdgcn_readlane(src_k, j);
-                    const uint32_t ppj = (uint32_t)__builtin_amdgcn_readlane((int)src_pp, j);
-                    if (grp == gg) { gk = kj; gsx = sxj; gsy = syj; gpp = ppj; gbig = src_big ? 1 : 0; ld = true; }
+            if (won) { k = f; spec = false; }
+            else {
+                // a free slot (the cursor has passed its seed) and a seed left to hand out?
+                const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
+                bool took = false;
+                if (freem && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - 2 * NW) {
+                    int k0 = 0;
+                    if (lane == 0) k0 = atomicAdd(&s_next, 1);
+                    k0 = __builtin_amdgcn_readfirstlane(k0);
+                    if (k0 < nseeds) { k = k0; slot = __builtin_ctzll(freem); spec = true; took = true; }
                 }
-                if (!src_big) ch_pend = src_pend;          // (what is left of the chunk; claimed R_BIG seeds never outnumber the idle groups)
-                if (!tw_small) {                           // the cache held grow()'s tiles (other word format, no member bytes)
-                    if (lane < NT) g_ttag[wave][lane] = -1;
-                    tw_small = true;
+                if (!took) {
+                    if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
+                    // nothing moved: every slot waits for the cursor, or nothing is left to hand out.  Sleep long enough that the
+                    // polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
+                    if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
+                    adv = true;                            // (look at the cursor again before asking for a job)
+                    LT(ST_WAIT);
+                    continue;
                 }
-                // the seed's own word: used meanwhile (:222)?  The others start with their own pixel (:515-520)
-                uint32_t sw = 1u;
-                if (ld && kq == 0) sw = c.pw[gpp];
-                sw = (uint32_t)__builtin_amdgcn_ds_bpermute((lane & 56) << 2, (int)sw);
-                const bool used = ld && (sw & 3u) != 0u;
-                if (ld && !used) {
-                    float s0, c0;
-                    fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
-                    gC = (double)c0; gS = (double)s0; gn = 1; gi = 0; gex = 1; gsnap = snap;
-                    gxu = 0; gxs = 0.0; gxc = 0.0; ebase = -8;
-                    if (kq == 0) {
-                        gring[0] = pack_xy(gsx, gsy);
-                        (gbuf0 + (size_t)gbi * glcap)[0] = pack_xy(gsx, gsy);
-                        atomicOr(&st8[gpp >> 2], gbit << (8 * (gpp & 3u)));                       // :520
-                        const int slot = tile_slot(gsx >> 3, gsy >> 3);
-                        if (g_ttag[wave][slot] == tile_key(gsx >> 3, gsy >> 3)) {
-                            const int cell = (slot << 6) | ((gsy & 7) << 3) | (gsx & 7);
-                            atomicOr(&mb32[cell >> 2], gbit << (8 * (cell & 3)));
-                        }
-                    }
-                }
-                if (ballot64(ld && !used)) gdirty = true;
-                if (ld && used) {
-                    if (kq == 0) st_st(&rg.state[gk & (RW - 1)], R_SKIP);
-                    gk = -1;
-                }
-                if (ballot64(used)) adv = true;
-                progress = true;
-                DSTAT(ST_SLOW, 1);                          // (refill rounds)
-                LT(ST_TREFILL);
             }
         }
-        if (ballot64(gk >= 0)) {
-            // ---- the groups' steps (until one of them has finished, at most 32) ----
-            if (gdirty) { wg_fence(); gdirty = false; }
-            (void)group_run(&gs, c.wave, 32);
-            gdirty = true;                                   // (its stores may be in flight)
-            const bool act = gk >= 0;
-            const bool fin = act & (gs.gfin != 0), bail = gs.gfin == 2;
-            uint32_t* const gbuf = gbuf0 + (size_t)gbi * glcap;                  // this group's list in HBM (all of it)
-            const unsigned long long finm = ballot64(fin & (kq == 0));
-            if (finm) {
-                // the region's member bits go (curMap is per region, :519), and with them the box of everything examined (the list's
-                // pixels and their 8-neighbourhoods; relative to the seed, used for the regions below regThre only)
-                if (gdirty) { wg_fence(); gdirty = false; }
-                int bx0 = 16, by0 = 16, bx1 = 16, by1 = 16;
-                for (int base = 0; ballot64(fin & (base < gn)); base += 8) {
-                    const int ix = base + kq;
-                    if (fin & (ix < gn)) {
-                        const uint32_t et = gn - ix <= SCAP ? gring[ix & (SCAP - 1)] : gbuf[ix];
-                        const int x = (int)(et & 0xffffu), y = (int)(et >> 16);
-                        const uint32_t q = (uint32_t)(y * w + x);
-                        atomicAnd(&st8[q >> 2], ~(gbit << (8 * (q & 3u))));
-                        const int slot = tile_slot(x >> 3, y >> 3);
-                        if (g_ttag[wave][slot] == tile_key(x >> 3, y >> 3)) {
-                            const int cl2 = (slot << 6) | ((y & 7) << 3) | (x & 7);
-                            atomicAnd(&mb32[cl2 >> 2], ~(gbit << (8 * (cl2 & 3))));
-                        }
-                        const int rx = min(max(x - gsx, -15), 15) + 16, ry = min(max(y - gsy, -15), 15) + 16;
-                        bx0 = min(bx0, rx); bx1 = max(bx1, rx); by0 = min(by0, ry); by1 = max(by1, ry);
-                    }
-                }
-                bx0 = imin8(bx0); bx1 = imax8(bx1); by0 = imin8(by0); by1 = imax8(by1);
-                gdirty = true;
-                const bool light = fin & !bail & ((double)gn < g.regThre);        // :228
-                // a grown region goes to its full evaluation with its list: the buffer changes hands, the group takes a free one
-                bool grown = fin & !bail & !light;
-                int nbuf = -1;
-                if (ballot64(grown)) {
-                    for (int gg = 0; gg < 8; gg++) {                              // (one group at a time: they share the wave's free mask)
-                        if (!((ballot64(grown) >> (8 * gg)) & 1ull)) continue;
-                        const int fm = lds_ld(&s_gfree[wave]);
-                        const int pick = fm ? __builtin_ctz(fm) : -1;
-                        if (pick >= 0 && lane == 0) atomicAnd(&s_gfree[wave], ~(1 << pick));
-                        if (grp == gg) nbuf = pick;
-                    }
-                    DSTAT(ST_GNOBUF, __builtin_popcountll(ballot64(grown & (nbuf < 0) & (kq == 0))));
-                    grown = grown & (nbuf >= 0);                                  // (no buffer left: the seed waits as R_BIG)
-                }
-                if (fin & (kq == 0)) {
-                    const int r = gk & (RW - 1);
-                    rg.snap[r] = (uint16_t)gsnap;
-                    if (light) {
-                        rg.aux[r] = (uint32_t)(bx0 - 1 + 16) | ((uint32_t)(by0 - 1 + 16) << 6) | ((uint32_t)(bx1 + 1 + 16) << 12) | ((uint32_t)(by1 + 1 + 16) << 18);
-                        if (trace) { rnum[r * 2] = gn; rnum[r * 2 + 1] = gn << 2; }
-                    } else if (grown) {
-                        rg.aux[r] = (uint32_t)(wave * GB + gbi);
-                        s_gn[wave * GB + gbi] = gn;
-                    }
-                    st_st(&rg.state[r], light ? R_LIGHT : (grown ? R_GROWN : ((gbig != 0 || !grow_big) ? R_FULL : R_BIG)));
-                }
-                if (grown) gbi = nbuf;
-                const unsigned long long lightm = ballot64(light & (kq == 0));
-                const int nbg = __builtin_popcountll(finm & ~lightm);
-                const int ngr = grow_big ? __builtin_popcountll(ballot64(fin & !light & !grown & (gbig == 0) & (kq == 0))) : 0;   // R_BIG: to be grown near the cursor
-                if (lane == 0 && nbg - ngr) atomicAdd(&s_nbig, nbg - ngr);
-                if (lane == 0 && ngr) atomicAdd(&s_ngrow, ngr);
-                int gsum = 0;
-                for (unsigned long long t = lightm; t; t &= t - 1ull) gsum += __builtin_amdgcn_readlane(gn, __builtin_ctzll(t));
-                STAT(ST_GROW, __builtin_popcountll(lightm)); STAT(ST_GROWN, gsum); DSTAT(ST_SMALLBAIL, nbg);
-                gk = fin ? -1 : gk;
-                adv = true;
-            }
-            LT(ST_TSMALL);
-            nwait = 0;
-            continue;
+        // The seed's pixel comes out of a window of 64 consecutive seeds kept in registers (lane j: seed win_k0 + j): three
+        // dependent loads (seed index -> sorted list -> pixel word) per 64 seeds instead of per seed, and the seeds already used
+        // when the window was loaded -- two thirds of them on the bench maps, once used is always used (:222) -- cost no load at all.
+        if (k < win_k0 || k >= win_k0 + 64) {
+            win_k0 = k;
+            const bool wv = k + lane < nseeds;
+            win_pp = wv ? ord[seedidx[k + lane]] : 0u;
+            win_used = ballot64(wv && (c.pw[win_pp] & 3u) != 0u);
         }
-        int k = -1, slot = 0;
-        bool spec = false;
-        bool adoptl = false;
-        if (pend_k >= 0) { k = pend_k; spec = pend_spec; slot = pend_slot; adoptl = pend_grown; pend_k = -1; pend_grown = false; nwait = 0; }
-        else {
-            if (progress) { nwait = 0; continue; }
-            if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
-            // Watchdog: the protocol has no state in which every wave waits; should one arise all the same (a defect), the image
-            // is given up after seconds of nobody moving instead of hanging the device: counts[img] = -1, the state goes to stats.
-            if (lds_ld(&s_commit) != f) nwait = 0;
-            if (++nwait > LSD_REGION_WATCHDOG || lds_ld(&s_abort)) {
-                if (b.stats && lane == 0) {
-                    long long* st = b.stats + img * kStatWords;
-                    if (!lds_ld(&s_abort)) {
-                        const int fc = lds_ld(&s_commit);
-                        st[40] = fc; st[41] = lds_ld(&s_next); st[42] = nseeds; st[43] = fc < nseeds ? st_ld(&rg.state[fc & (RW - 1)]) : -1;
-                        st[44] = lds_ld(&s_nbig); st[45] = lds_ld(&s_lock); st[46] = pend_k; st[47] = wave;
-                    }
-                    // what this wave holds (developer record)
-                    st[24 + 2 * wave] = (long long)ch_k0 | ((long long)(pend_k + 1) << 32);
-                    st[25 + 2 * wave] = (long long)ch_pend;
-                }
-                if (lane == 0) lds_st(&s_abort, 1);
-                break;
-            }
-            // nothing to do: every slot waits for the cursor, the ring is full, or nothing is left to hand out.  Sleep long
-            // enough that the polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
-            if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
-            adv = true;                                    // (look at the cursor again before asking for a job)
-#ifdef LSD_REGION_STATS
-            {   // why this wave had nothing to do: no result slot for a waiting seed / the ring is full / no seed is left
-                const int old = lds_ld(&s_next);
-                const long long t_ = NOW();
-                const int why = old >= nseeds ? ST_WNOSEED : (lds_ld(&s_nbig) > 0 ? ST_WNOSLOT : (old + CH - f > RW ? ST_WRING : ST_WAIT));
-                DSTAT(why, t_ - tl); tl = t_;
-            }
-#else
-            LT(ST_WAIT);
-#endif
-            continue;
-        }
-        // ---- a full evaluation of seed k (RegionGrower ... RectangleImprover with all 64 lanes) ----
-        const uint32_t pp = seedpos[k];
+        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)win_pp, k - win_k0);
+        const bool skip_known = ((win_used >> (k - win_k0)) & 1ull) != 0ull;
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
         int outcome = 0, num = 0, num0 = 0;
@@ -2182,28 +1502,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         double pv = 0;                                     // lane j < 12: field j of the result's rectangle (structRec order)
         int rec_pk = 0;
         // ---- evaluate ----
-        int epoch_snap = lds_ld(&s_epoch);                 // before anything of usedMap is read for this seed
+        if (lane == slot && spec) slot_k_l = k;            // the slot is taken until the cursor has passed seed k
+        const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
         wg_fence();
-        // a region grown by the group grower: its list waits in a buffer, and what it saw of usedMap is its group's snapshot
-        const int abuf = adoptl ? (int)rg.aux[k & (RW - 1)] : 0;
-        const int an = adoptl ? s_gn[abuf] : 0;
-        if (adoptl) {
-            const int now = epoch_snap;
-            epoch_snap -= (epoch_snap - (int)rg.snap[k & (RW - 1)]) & 0xffff;
-            // evaluated at the cursor, the result is committed without the check a speculative one gets there: the list is only
-            // what RegionGrower would return NOW if no line accepted since the group's snapshot has banned a pixel it examined
-            if (!spec && now != epoch_snap && examined_hit(b.glists + (img * (size_t)(NW * GB) + abuf) * b.glcap, an, epoch_snap)) {
-                adoptl = false;
-                epoch_snap = now;
-                if (lane == 0) atomicOr(&s_gfree[abuf / GB], 1 << (abuf % GB));
-            }
-        }
-        if (tw_small || !spec || epoch_snap != g_ws[wave].cache_epoch) {   // tiles fetched before the last accept may miss its bans
+        if (!spec || epoch_snap != g_ws[wave].cache_epoch) {   // tiles fetched before the last accept may miss its bans
             invalidate_tiles(c);
             g_ws[wave].cache_epoch = epoch_snap;
-            tw_small = false;
         }
-        const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
+        const bool skip = skip_known || (c.pw[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
         uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
@@ -2217,8 +1523,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             double tol = g.degThre, regdeg = seedDeg;
             bool done = false;
             for (int pass = 0; pass < 2 && !done; pass++) {
-                if (pass == 0 && adoptl) num = adopt_list(c.wave, b.glists + (img * (size_t)(NW * GB) + abuf) * b.glcap, an);
-                else num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
+                num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
                 if (pass == 0 && spec && num <= b.gcap) {              // keep the first list for the validation at the cursor
                     for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
                     n1 = num;
@@ -2253,8 +1558,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 rec_pk = g_ws[wave].rec.pk;
             }
         }
-        if (adoptl && lane == 0) atomicOr(&s_gfree[abuf / GB], 1 << (abuf % GB));      // the list buffer is free again
-        DSTAT(ST_GADOPT, adoptl ? 1 : 0);
         const int gnum = g_ws[wave].gnum;                  // size of the last grow (grow order)
         const bool has_copy = g_ws[wave].has_copy != 0;
 
@@ -2265,14 +1568,13 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (!skip && outcome >= 2) commit_marks(k, num0, num, outcome, logNFA, pv, nullptr, 0);
             else if (!skip) write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             wg_fence();
-            if (lane == 0) { rg.state[k & (RW - 1)] = (uint8_t)R_EMPTY; lds_st(&s_commit, k + 1); }
+            if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
             LT(ST_TCOMMIT);
-            adv = true;
             continue;
         }
         if (skip) {
             if (lane == slot) slot_k_l = -1;               // nothing kept in the slot
-            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_SKIP);
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
             adv = true;
             continue;
         }
@@ -2294,15 +1596,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (n1 > 32767 || n2 > 32767) precise = false;     // (the sizes travel in 15-bit fields)
         if (outcome <= 1) {                                // nothing to mark: publish and move on
             if (lane == 0) {
-                const int r = k & (RW - 1), si = wave * NS + slot;
-                rg.snap[r] = (uint16_t)epoch_snap;
-                rg.aux[r] = (uint32_t)si;
-                stab.box[si][0] = (short)x0; stab.box[si][1] = (short)y0; stab.box[si][2] = (short)x1; stab.box[si][3] = (short)y1;
-                stab.lcnt[si] = precise ? ((uint32_t)(n1 + 1) | ((uint32_t)n2 << 16)) : 0u;
+                const int r = k & (RW - 1);
+                rg.snap[r] = epoch_snap;
+                rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
+                rg.lref[r] = precise ? (uint32_t)(wave * NS + slot) : ~0u;
+                rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
                 if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
             }
             wg_fence();                                    // the lists are in the slot before the record says so
-            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_LIGHTL);
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
             adv = true;
             continue;
         }
@@ -2337,7 +1639,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
         }
         if (redo) {
-            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_REDO);
+            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
             STAT(ST_REDO, 1);
             adv = true;
             continue;
@@ -2350,22 +1652,25 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
             P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
             P[23] = (double)epoch_snap;
-            rg.aux[k & (RW - 1)] = (uint32_t)(wave * NS + slot);
+            rg.lref[k & (RW - 1)] = (uint32_t)(wave * NS + slot);
         }
         wg_fence();                                        // record and lists are in the slot before the ring says so
-        if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_STASH);
+        if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_STASH);
         adv = true;
     }
 
     __syncthreads();
     if (threadIdx.x == 0) {
-        b.counts[img] = s_abort ? -1 : s_lines;
+        b.counts[img] = s_lines;
         if (b.nseed) b.nseed[img] = s_ntrace;
     }
     if (b.stats) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
-        if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; }
-        if (lane < ST_COUNT && !s_abort && (sslot(lane) != 11 || kStatSlots == ST_COUNT)) atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 32);
+        if (lane == 0 && wave == 0) { g_stat[c.wave][ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][ST_SEEDS] = (unsigned long long)nseeds; }
+        if (lane < ST_COUNT) {
+            if (lane == ST_MAXREG) atomicMax(&st[lane], g_stat[c.wave][lane]);
+            else atomicAdd(&st[lane], g_stat[c.wave][lane]);
+        }
     }
 }
 
@@ -2379,7 +1684,6 @@ void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, 
 int region_slots() { return w8::NS; }
 int region_waves() { return w8::NW; }
 int region_ring() { return w8::RW; }
-int region_gbufs() { return w8::GB; }
 #else
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
     hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base);

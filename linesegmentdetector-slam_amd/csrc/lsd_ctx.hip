@@ -21,8 +21,8 @@ struct lsd_ctx {
     int device = 0;
     int num_cus = 256;                 // compute units of the device
     uint32_t id_budget = 0xFFFF0u;     // curMap stamp ids a wave may use per run before it clears its stamps (lsd_debug_set_stamp_budget)
-    int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: per-variant default), see k_region.hip
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
+    bool prefer4 = false;              // the 8-wave workspace did not fit this device's memory once: batches run on 4 waves per image
     hipStream_t stream = nullptr;      // the context's own stream
     hipStream_t last_stream = nullptr; // stream of the last enqueue
     std::string err;
@@ -35,7 +35,7 @@ struct lsd_ctx {
     double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
     double2* sc = nullptr;
     uint32_t* order = nullptr;
-    uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr, *seedpos = nullptr, *tepoch = nullptr, *stamp8 = nullptr, *glists = nullptr;
+    uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr;
     uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number (a wave that uses up its 2^20 clears its stamps)
     uint32_t* slist = nullptr;
     double* pend = nullptr;
@@ -43,7 +43,6 @@ struct lsd_ctx {
     int* rnum = nullptr;
     int mcap = 16384;
     int gcap = 8192;
-    int glcap = 4096;                  // entries of a list buffer of the group grower (a longer region is grown by grow())
     uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
@@ -55,6 +54,7 @@ struct lsd_ctx {
     int32_t *h_counts = nullptr, *h_offs = nullptr;
     uint8_t* pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_used[2] = {false, false};  // a DMA through the buffer has been queued: its event must be waited for before the buffer is written again
     hipStream_t copy_stream = nullptr;  // second stream: the remapped maps travel back while the rest of the pipeline runs
     size_t hcap_n = 0, hcap_wh = 0;
     int hcap_max_lines = 0;
@@ -184,7 +184,9 @@ static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStre
         pr /= 2.0;                                                                          // :1085,:1149
     }
     HIPCHK(c, hipStreamSynchronize(s));
-    if (c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));     // kernels of an earlier enqueue may still read the tables
+    // kernels of an earlier enqueue (on whatever stream, which may be gone by now) may still read the tables: wait for the event
+    // that enqueue recorded, never for its stream
+    if (c->done_valid) HIPCHK(c, hipEventSynchronize(c->ev_done));
     HIPCHK(c, hipMemcpy(c->d_taps, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_ptab, pt, sizeof(pt), hipMemcpyHostToDevice));
     c->tab_params = *p;
@@ -204,7 +206,9 @@ static hipError_t re_alloc(T** p, size_t count) {
 static int waves_for(const lsd_ctx* c, int n) {
     // 8 wavefronts per image (one image per CU) finish an image ~1.5x sooner; 4 (two images per CU) have the higher throughput.
     // While the batch is only a few images per CU its time is that of its heaviest images: 8.  Long batches: 4.
-    if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && n <= 4 * c->num_cus)) return 8;
+    // (the per-wave workspace -- stamps / spill / gcopy, 12 B per scaled pixel and wave, + result slots -- doubles with 8 waves:
+    //  18.5 GB for the 512 x 2048^2 bench batch, ~37 GB for 1024 such maps; if it cannot be allocated the context falls back to 4)
+    if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && !c->prefer4 && n <= 4 * c->num_cus)) return 8;
     return 4;
 }
 
@@ -221,18 +225,15 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->sc, tot));
         HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
-        HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
+        HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
-        HIPCHK(c, re_alloc(&c->stamp8, ws * ((pp + 3) / 4)));
-        HIPCHK(c, hipMemset(c->stamp8, 0, ws * ((pp + 3) / 4) * sizeof(uint32_t)));   // (every region clears its own bits again)
         c->run_id = 0;
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->pend, gs * 24));
-        HIPCHK(c, re_alloc(&c->glists, ws * (size_t)region_gbufs() * (size_t)c->glcap));
         HIPCHK(c, re_alloc(&c->order, nn));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
-        HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
+        HIPCHK(c, re_alloc(&c->stats, nn * 32)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
         c->cap_n = nn; c->cap_npx = pp; c->cap_gpx = gg; c->cap_ws = ws;
@@ -254,16 +255,21 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
 // A failed (re)allocation leaves some arrays freed and others at their old size: forget the whole workspace, so that the next
 // call starts from nothing instead of trusting stale capacities.
 static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
-    const int st = ensure_workspace_impl(c, n, npx, gpx, max_lines, trace);
+    int st = ensure_workspace_impl(c, n, npx, gpx, max_lines, trace);
     if (st != LSD_OK) {
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->stamp8, (void**)&c->glists, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
+                         (void**)&c->seedidx, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
         c->cap_n = c->cap_npx = c->cap_gpx = c->cap_ws = 0; c->cap_max_lines = 0; c->cap_trace = false;
+        if (st == LSD_ERR_NOMEM && c->region_waves_mode == 0 && !c->prefer4 && waves_for(c, (int)n) == 8) {
+            // the 8-wave variant's workspace does not fit: once more with 4 wavefronts per image (half the per-wave arrays)
+            c->prefer4 = true;
+            return ensure_workspace(c, n, npx, gpx, max_lines, trace);
+        }
     }
     return st;
 }
@@ -321,13 +327,6 @@ int lsd_create(lsd_ctx** out, int device) {
         if (hipHostMalloc((void**)&c->pin[k], kPinBytes, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_NOMEM; }
     c->last_stream = c->stream;
-    {   // experiments: LSD_REGION_SOFT / _CLAIM / _FEED / _BIG override the schedule of the region stage
-        const char* e;
-        if ((e = getenv("LSD_REGION_SOFT"))) c->tun_soft = atoi(e);
-        if ((e = getenv("LSD_REGION_CLAIM"))) c->tun_claim = atoi(e);
-        if ((e = getenv("LSD_REGION_FEED"))) c->tun_feed = atoi(e);
-        if ((e = getenv("LSD_REGION_BIG"))) c->tun_big = atoi(e);
-    }
     *out = c;
     return LSD_OK;
 }
@@ -336,7 +335,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->stamp8, c->glists, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -406,16 +405,10 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
-    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch; b.stamp8 = c->stamp8; b.glists = c->glists; b.glcap = c->glcap;
+    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx;
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
-    {
-        const int nw = waves_for(c, n);
-        b.tun_soft = c->tun_soft > 0 ? c->tun_soft : 64 * nw;      // seeds the hand-out runs ahead of the cursor
-        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 48 * nw;   // how far ahead of the cursor a full evaluation may start
-        b.tun_feed = c->tun_feed; b.tun_big = c->tun_big;
-    }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
 
@@ -438,9 +431,9 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * c->cap_npx * sizeof(uint32_t), s));
             c->run_id = 1;
         }
-        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));
-        HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), s));
-        // 8 wavefronts per image take a whole CU each: worth it while the batch leaves CUs idle (<= one image per CU)
+        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * 32 * n, s));
+        // 8 wavefronts per image take a whole CU each: worth it up to four images per CU (waves_for); the per-wave workspace
+        // (stamps / spill / gcopy: 12 B per scaled pixel and wave) was sized for it by ensure_workspace
         const bool wide = waves_for(c, n) == 8;
         if (wide) launch_region_w8(g, b, n, c->run_id << 20, s);
         else launch_region_w4(g, b, n, c->run_id << 20, s);
@@ -478,10 +471,11 @@ static int h2d_staged(lsd_ctx* c, void* dst, const void* src, size_t bytes, hipS
     for (int k = 0; off < bytes; k++) {
         const int b = k & 1;
         const size_t len = bytes - off < kPinBytes ? bytes - off : kPinBytes;
-        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
+        if (c->pin_used[b]) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));   // (also a DMA left behind by a call that returned with an error)
         memcpy(c->pin[b], (const uint8_t*)src + off, len);
         HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + off, c->pin[b], len, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipEventRecord(c->pin_ev[b], s));
+        c->pin_used[b] = true;
         off += len;
     }
     return LSD_OK;
@@ -492,8 +486,10 @@ static int d2h_staged(lsd_ctx* c, void* dst, const void* src, size_t bytes, hipS
     for (int k = 0; off < bytes; k++) {
         const int b = k & 1;
         const size_t len = bytes - off < kPinBytes ? bytes - off : kPinBytes;
+        if (c->pin_used[b] && k < 2) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
         HIPCHK(c, hipMemcpyAsync(c->pin[b], (const uint8_t*)src + off, len, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(c->pin_ev[b], s));
+        c->pin_used[b] = true;
         if (prev_len) {
             HIPCHK(c, hipEventSynchronize(c->pin_ev[b ^ 1]));
             memcpy((uint8_t*)dst + prev_off, c->pin[b ^ 1], prev_len);
@@ -518,7 +514,7 @@ static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, b
         HIPCHK(c, re_alloc(&c->h_in, nn * ww));
         HIPCHK(c, re_alloc(&c->h_lineim, li ? nn * ww : 0));
         HIPCHK(c, re_alloc(&c->h_lines, nn * (size_t)ml)); HIPCHK(c, re_alloc(&c->h_flat, nn * (size_t)ml));
-        HIPCHK(c, re_alloc(&c->h_counts, nn)); HIPCHK(c, re_alloc(&c->h_offs, nn + 1));
+        HIPCHK(c, re_alloc(&c->h_counts, nn)); HIPCHK(c, re_alloc(&c->h_offs, nn + 2));
         c->hcap_n = nn; c->hcap_wh = ww; c->hcap_max_lines = ml; c->hcap_lineim = li;
     }
     return LSD_OK;
@@ -534,6 +530,7 @@ int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const ls
     HIPCHK(c, hipSetDevice(c->device));
     const size_t wh = (size_t)cols * rows;
     const int ml = c->host_max_lines;
+    if ((long long)n * ml >= (1ll << 31) / 10) return LSD_ERR_UNSUPPORTED;   // (int32 offsets into the flat record array)
     st = ensure_host_staging(c, (size_t)n, wh, ml, line_ims != nullptr);
     if (st != LSD_OK) return st;
     hipStream_t s = c->stream;
@@ -548,22 +545,19 @@ int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const ls
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev[1], 0));
     st = d2h_staged(c, maps, c->h_in, (size_t)n * wh, c->copy_stream);
     if (st != LSD_OK) return st;
-    st = d2h_staged(c, offsets_out, c->h_offs, sizeof(int32_t) * (size_t)(n + 1), s);          // (waits for the pipeline)
+    std::vector<int32_t> offs((size_t)n + 2);                                                  // offsets[n + 1], then the overflow count
+    st = d2h_staged(c, offs.data(), c->h_offs, sizeof(int32_t) * (size_t)(n + 2), s);          // (waits for the pipeline)
     if (st != LSD_OK) return st;
+    memcpy(offsets_out, offs.data(), sizeof(int32_t) * (size_t)(n + 1));
     const int total = offsets_out[n];
     lsd_line* out = (lsd_line*)calloc(total > 0 ? total : 1, sizeof(lsd_line));
     if (!out) return LSD_ERR_NOMEM;
     st = total > 0 ? d2h_staged(c, out, c->h_flat, sizeof(lsd_line) * (size_t)total, s) : LSD_OK;
     if (st == LSD_OK && line_ims) st = d2h_staged(c, line_ims, c->h_lineim, (size_t)n * wh, s);
     if (st != LSD_OK) { free(out); return st; }
-    // more lines than host_max_lines in some image: the first host_max_lines of it are returned, and the status says so
-    std::vector<int32_t> counts(n);
-    st = d2h_staged(c, counts.data(), c->h_counts, sizeof(int32_t) * (size_t)n, s);
-    if (st != LSD_OK) { free(out); return st; }
-    int status = LSD_OK;
-    for (int i = 0; i < n; i++) if (counts[i] > ml) status = LSD_ERR_CAPACITY;
     *lines_out = out;
-    return status;
+    // more lines than host_max_lines in some image: the first host_max_lines of it are returned, and the status says so
+    return offs[(size_t)n + 1] > 0 ? LSD_ERR_CAPACITY : LSD_OK;
 }
 
 int lsd_set_host_max_lines(lsd_ctx* c, int max_lines) {
@@ -630,7 +624,7 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * kStatWords; need = 8 * kStatWords; break;
+        case LSD_DBG_STATS: src = c->stats + (size_t)image * 32; need = 256; break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

@@ -9,7 +9,6 @@ namespace lsdhip {
 constexpr double kPi = 3.14159265358979323846;  // == 4.0*atan(1.0), myLSD.cpp:9
 constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per phase kernel
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries
-constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
 
 // Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
@@ -48,13 +47,11 @@ struct Buffers {
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
     uint32_t* pw;          // n x npx : packed pixel word (see above)
     uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3 (never initialised, read only behind code 3)
-    uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
     uint16_t* ordv;        // n x npx : bin values
     uint32_t* stamps;      // n x NW x npx : per-wave curMap stamps of the region stage
-    uint32_t* stamp8;      // n x NW x ceil(npx/4) : a byte per pixel and wave: bit g = member of the region lane group g is growing
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
     float4* wmeta;         // n x NW x mcap : per list entry (unit sum vector, sin of the smallest slack) of its last neighbourhood test
@@ -62,13 +59,9 @@ struct Buffers {
     int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
     uint32_t* order;       // n : image indices, heaviest (largest nb) first: the region stage's workgroup -> image map
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
-    uint32_t* seedpos;     // n x npx : their pixels (y*w+x), same order
-    uint32_t* glists;      // n x NW x GB x glcap : region lists of the group grower (GB list buffers per wave)
-    int glcap;
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
     uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())
-    int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
@@ -83,7 +76,7 @@ struct Buffers {
     // debug
     void* seeds;           // n x npx trace records or null
     int32_t* nseed;        // n
-    long long* stats;      // n x kStatWords
+    long long* stats;      // n x 8
 };
 
 struct SeedRec {  // mirrors oracle's orc_seed
@@ -103,7 +96,6 @@ void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, 
 int region_slots();    // result slots per wavefront (slist and pend are sized x this)
 int region_waves();    // wavefronts per image of the wider variant: what the workspace is sized for
 int region_ring();     // commit-ring records per image (rnum is sized x this x 2)
-int region_gbufs();    // list buffers per wavefront of the group grower (glists is sized x this x glcap)
 void launch_calib(double* buf, size_t n, hipStream_t s);
 void launch_match(const double* map_cache, int cols, int rows, const lsd_line* map_lines, const lsd_line* scan_lines,
                   const double* pts, int n_points, double lidx, double lidy, double lastx, double lasty, const int* pairs,

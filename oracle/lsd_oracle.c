@@ -821,7 +821,8 @@ int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
             while (angDiff > 180) angDiff -= 360;
             o->pos.ang = angDiff;
             const double numAllPoint = n_points;
-            if (numValidPoint < 0.7 * numAllPoint) o->score = INFINITY;      /* :388-392 */
+            if (n_points == 0) o->score = INFINITY;                          /* :248-263: RSI.numScanImPoint == 0, CalcScore is not called */
+            else if (numValidPoint < 0.7 * numAllPoint) o->score = INFINITY; /* :388-392 */
             else o->score = (sumValidDist + sumMaxDist) / (numValidPoint) + 10 * (numAllPoint - numValidPoint) / numAllPoint;
         }
     }

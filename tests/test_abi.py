@@ -183,6 +183,25 @@ def test_cpp_adapter_in_the_reference_include_order(case, tmp_path):
     assert p.returncode == 0, p.stderr
 
 
+def test_cpp_adapter_wins_over_a_second_myLSD_h_on_the_path(tmp_path):
+    """The reference compiles with -I LSD and includes <myLSD.h> with angle brackets (LSD/main_on_windows.cpp:5), and the
+    adapter has the same file name: -I<repo>/include must come BEFORE -I LSD.  With both
+    directories on the path the adapter is the one that is found first, takes the reference's baseFunc.h from the second
+    directory, and the reference's own myLSD.h (a stand-in here: it would need OpenCV) is never opened; in the wrong order
+    the build fails loudly."""
+    inc = os.path.join(ROOT, "include")
+    ref = tmp_path / "LSD"
+    ref.mkdir()
+    (ref / "baseFunc.h").write_text(_BASEFUNC_DOUBLE)
+    (ref / "myLSD.h").write_text("#error the reference's LSD/myLSD.h was picked up: put -I<repo>/include before -I LSD\n")
+    src = tmp_path / "caller.cpp"
+    src.write_text(_CALLER % "#include <myLSD.h>\n#include <baseFunc.h>\n#ifndef TEST_SAW_REFERENCE_BASEFUNC\n#error baseFunc.h of the reference tree expected\n#endif")
+    ok = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", inc, "-I", str(ref), str(src)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    bad = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(ref), "-I", inc, str(src)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "put -I<repo>/include before -I LSD" in bad.stderr
+
+
 def test_cpp_adapter_opencv_branch_compiles(tmp_path):
     """The LSD_WITH_OPENCV branch (cv::Mat in the signatures, as the reference's callers pass it) through a compiler:
     against a test double of <opencv2/core.hpp> with cv::Mat's surface that the adapter uses (zeros -> MatExpr, ptr<T>(row),

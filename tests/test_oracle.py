@@ -258,3 +258,13 @@ def test_libm_tie_images_document_the_one_caveat(name, oracle):
     first = next(i for i, (x, y) in enumerate(zip(sa, sb)) if x["outcome"] != y["outcome"] or x["logNFA"] != y["logNFA"])
     assert sa[first]["num"] == sb[first]["num"] and sa[first]["final_num"] == sb[first]["final_num"]   # same region, other NFA count
     assert {int(sa[first]["outcome"]), int(sb[first]["outcome"])} == {2, 3}
+
+
+def test_scan_to_map_match_without_scan_points_is_rejected(maps, oracle):
+    """myFA.cpp:248-263: a rotated scan image without points (RSI.numScanImPoint == 0) is not scored, the candidate gets
+    INFINITY -- not the 0/0 CalcScore's formula would give."""
+    mc = np.ones((40, 50), np.float64)
+    ln = np.zeros(1, oracle.LINE_DTYPE)
+    ln["x1"], ln["y1"], ln["x2"], ln["y2"] = 5, 5, 30, 5
+    out = oracle.scan_to_map_match(mc, ln, ln, np.zeros((0, 3)), (10.0, 10.0, 0.0), (-1.0, -1.0, 0.0), np.array([[0, 0]], np.int32))
+    assert out.shape == (1, 4, 4) and np.all(np.isinf(out[0, :, 3])) and np.all(np.isfinite(out[0, :, :3]))
