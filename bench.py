@@ -64,6 +64,15 @@ def make_batch(maps, n, size, first=0):
     return out
 
 
+def source_sha():
+    """Identifies the kernel sources a number was measured on (sha1 over csrc/*.hip, *.h): the PMC traffic file carries the same."""
+    import glob, hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "linesegmentdetector-slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "linesegmentdetector-slam_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def load_maps():
     z = np.load(os.path.join(ROOT, "tests", "golden", "maps.npz"))
     return {k: z[k] for k in z.files}
@@ -115,6 +124,14 @@ def cpu_baseline(size, first, sample=24, reps=5):
         r = oracle.lsd(m, want_lineim=True)
         t1.append(time.perf_counter() - t0)
     out["map1"] = {"ms": min(t1[1:]) * 1e3, "lines_per_s": len(r["lines"]) / min(t1[1:]), "kind": "port"}
+    img0 = make_image(load_maps(), first, size)                     # the port on ONE image of the batch (what single_image_latency_ms times on the GPU)
+    t0s = []
+    for _ in range(4):
+        m = img0.copy()
+        t0 = time.perf_counter()
+        oracle.lsd(m, want_lineim=True)
+        t0s.append(time.perf_counter() - t0)
+    out["single_image_ms"] = min(t0s[1:]) * 1e3
     try:                                                            # N-core figure: N independent pinned instances over disjoint images
         import multiprocessing as mp
         per = max(4, sample // 3)
@@ -235,7 +252,9 @@ def main():
                 tj = json.load(open(tpath))
                 traffic = tj.get("k_gradient_bytes_per_launch")
                 traffic_all = {k: v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items()}
-                traffic_src = "profiles/traffic_latest.json (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run" % tj.get("build", "build not recorded")
+                same = tj.get("source_sha") == source_sha()
+                traffic_src = "profiles/traffic_latest.json (%s, kernel sources %s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run" % (
+                    tj.get("build", "build not recorded"), "identical to this run's (sha %s)" % source_sha() if same else "DIFFERENT from this run's: sha %s vs %s" % (tj.get("source_sha"), source_sha()))
             except Exception:
                 traffic = None
         # per-image cycles of the region stage (s_memtime, read after the timed region): the batch time is its heaviest images
@@ -247,12 +266,13 @@ def main():
         out = {
             "metric": "Mpixels/sec LSD (grad+grow+NFA)", "value": mpix / step_s, "unit": "Mpix/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "source_sha": source_sha(),
             "config": {"workload": "%d x %dx%d u8 occupancy maps %s tiled/rolled/flipped from 4 aisle-class fixtures "
                                    "(SURVEY 8d C4), full pipeline incl. lineIm, params 0.3/0.6/22.5/0.7/1024" % (
                                        a.batch, size, size, "per GPU" if a.scaling == "weak" else "in total, split over the GPUs"),
                        "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
-                       "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU"},
+                       "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU",
+                       "rccl_gather_in_step": bool(use_dist)},
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
             "kernel_ms": {k: v / a.steps for k, v in kt.items()},
             # informational: every kernel's HBM traffic (PMC, profiles/traffic_latest.json) over its live launch time
@@ -273,8 +293,21 @@ def main():
                                   "note": "SURVEY 8d algorithmic bytes of the whole path (K1+K2+K3+K5; %.1f MB per image) over the step time" % (alg_img / 1e6)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            extras(out, a, ctx, lsd, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size)
-            out["cpu_baseline"] = cpu_baseline(size, first)
+            extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total)
+            out["cpu_baseline"] = cb = cpu_baseline(size, first)
+            # same-box ratios: the GPU against the single-thread port on THIS host's cores (cpu_baseline.kind = "port": a port of the
+            # reference path that skips its two accidental full-image scans per region -- NOT the reference itself, which cannot
+            # be built here; the cross-host figure against the unmodified reference carries the host in its name)
+            m1 = out["map1"]
+            m1["vs_port_one_core"] = m1["batch512_lines_per_s"] / cb["map1"]["lines_per_s"]
+            if "cores" in cb.get("all_cores", {}):
+                m1["vs_port_all_cores"] = m1["batch512_lines_per_s"] / (cb["map1"]["lines_per_s"] * cb["all_cores"]["cores"])
+                m1["vs_port_all_cores_note"] = "map1 port lines/s x %d host cores (one independent instance per core assumed)" % cb["all_cores"]["cores"]
+            m1["single_call_vs_port"] = cb["map1"]["ms"] / m1["single_call_lsd_only_ms"]
+            out["single_image_latency_vs_port"] = cb["single_image_ms"] / out["single_image_latency_ms"]
+            out["vs_port_one_core"] = out["value"] / cb["value"]
+            if "value" in cb.get("all_cores", {}):
+                out["vs_port_all_cores"] = out["value"] / cb["all_cores"]["value"]
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -282,7 +315,7 @@ def main():
     ctx.close()
 
 
-def extras(out, a, ctx, lsd, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size):
+def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total):
     """Outside the timed region: what north_star asks for on mapValue_map1, single-image latency, device copy ceiling."""
     import torch
     ims = None if d_ims is None else d_ims.data_ptr()
@@ -328,10 +361,33 @@ def extras(out, a, ctx, lsd, maps, d_maps, d_lines, d_counts, d_ims, stream, dev
         "single_call_note": "host ABI (lsd_map_cache + lsd_run), wall clock incl. staging and PCIe, median of 20",
         "batch512_ms": tb * 1e3, "batch512_lines_per_s": reps * 7 / tb, "batch512_Mpix_per_s": reps * rows * cols / 1e6 / tb,
         "reference_single_thread": REF_MAP1, "reference_source": "BASELINE.md section 2 (unmodified reference, survey container)",
-        "lines_per_s_vs_reference": reps * 7 / tb / REF_MAP1["lines_per_s"],
-        "single_call_vs_reference": REF_MAP1["ms"] / statistics.median(lsd_only[2:]),
+        "lines_per_s_vs_reference_cross_host": reps * 7 / tb / REF_MAP1["lines_per_s"],
+        "single_call_vs_reference_cross_host": REF_MAP1["ms"] / statistics.median(lsd_only[2:]),
+        "cross_host_note": "numerator: this MI355X box; denominator: the unmodified reference on the survey container's 2.1 GHz Xeon (BASELINE.md section 2) -- "
+                           "the reference cannot be built on the GPU box; same-box ratios against the port: vs_port_one_core / vs_port_all_cores",
         "kernel_ms_batch512": ctx.timings()}
     del d1, l1, c1, i1
+    # -- strong scaling projected from ONE GPU (BASELINE configs[4]: the same batch split over 2 / 4 / 8 GPUs, contiguous shards):
+    #    every shard is run alone on this GPU; a step of the sharded job cannot be shorter than its slowest shard (+ the gather, 22 MB)
+    if a.scaling == "weak" and n_total >= 8:
+        def run_shard(lo, hi):
+            best = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.enqueue_device(d_maps[lo:hi].data_ptr(), hi - lo, size, size, d_lines[lo:hi].data_ptr(), a.max_lines, d_counts[lo:hi].data_ptr(),
+                                   d_line_ims=None if d_ims is None else d_ims[lo:hi].data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t1) * 1e3)
+            return best
+        t_all = run_shard(0, n_total)
+        proj = {"1": {"max_shard_ms": t_all, "speedup": 1.0}}
+        for world in (2, 4, 8):
+            ts = [run_shard(*ldist.shard_range(n_total, world, r)) for r in range(world)]
+            proj[str(world)] = {"max_shard_ms": max(ts), "min_shard_ms": min(ts), "speedup": t_all / max(ts)}
+        out["strong_scaling_projection"] = {"gpus": proj, "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
+                                            "the sharded step takes at least its slowest shard: the region stage gives one CU per image, so a shard "
+                                            "cannot finish before its heaviest image does" % n_total}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     src_t = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     dst_t = torch.empty_like(src_t)

@@ -142,6 +142,31 @@ int lsd_enqueue_scan_to_map_match_device(lsd_ctx *ctx, const double *d_map_cache
                                          lsd_position last_pose, const int *d_pairs, int n_pairs, double z_occ_max_dis,
                                          double max_esti_dist, lsd_match_score *d_out, void *stream);
 
+/* --- scan-line extraction batch (SURVEY 8f "next" #4) ------------------------------------------- */
+/* Replaces myrdp::FeatureScan (LSD/myRDP.cpp:9-185; RegionSegmentation :304-389, SplitMerge / SplitMergeAssistant :187-302,
+ * getThresholdDeltaDist :391-412; caller LSD/main_on_windows.cpp:127) for a BATCH of lidar scans: n_scans scans at a pitch of
+ * `stride` readings, scan i holding lens[i] <= stride finite readings (range, angle) -- what the caller's read loop leaves
+ * after dropping the infinite ranges (:115-121).  Per scan i:
+ *   lines_out[i * 360 .. ]   the line records (structLinesInfo) in the reference's order, n_lines[i] of them (<= 360, :39)
+ *   pts_out[i * pts_cap .. ] scanImPoint: the pixels of the lines' rasters (x, y, 0) in the reference's order; n_pts[i] is
+ *                            their number, of which the first pts_cap are stored
+ *   lidar_pos[2 i .. ]       structLidarPointRec lidarPos (x, y), :33-36;  im_size[2 i ..] = (cols, rows) of FS.lineIm, :31
+ * FS.lineIm itself is im_size zeros with 255 at the listed pixels.  region_point_limit / thre_line / line_dist_thre_m are
+ * rdp_leastPoint / rdp_threLine / rdp_leastDist (LSD/baseFunc.h:70-72: 3, 0.08, 0.5).  lens[i] <= 1024.
+ * lsd_polar is structLidarPointPolar (LSD/myRDP.h:34-38) without its `split` work flag; lsd_map_param is structMapParam
+ * (LSD/baseFunc.h:25-31). */
+typedef struct lsd_polar { double range, angle; } lsd_polar;
+typedef struct lsd_map_param { int oriMapCol, oriMapRow; double mapResol, mapOriX, mapOriY; } lsd_map_param;
+#define LSD_RDP_MAX_LINES 360
+int lsd_feature_scan_batch(lsd_ctx *ctx, const lsd_polar *scans, const int *lens, int n_scans, int stride, lsd_map_param map_param,
+                           int region_point_limit, double thre_line, double line_dist_thre_m, lsd_line *lines_out, int *n_lines,
+                           lsd_position *pts_out, int pts_cap, int *n_pts, double *lidar_pos, int *im_size);
+/* The same with every array resident on the device, asynchronous on `stream`. */
+int lsd_enqueue_feature_scan_batch_device(lsd_ctx *ctx, const lsd_polar *d_scans, const int *d_lens, int n_scans, int stride,
+                                          lsd_map_param map_param, int region_point_limit, double thre_line, double line_dist_thre_m,
+                                          lsd_line *d_lines_out, int *d_n_lines, lsd_position *d_pts_out, int pts_cap, int *d_n_pts,
+                                          double *d_lidar_pos, int *d_im_size, void *stream);
+
 /* --- wire format (SURVEY 8f "next" #3) ---------------------------------------------------------- */
 /* Replaces the cell loop of the ROS map callback (LSD/main_on_linux.cpp:108-124): nav_msgs/OccupancyGrid cells
  * (int8: -1 unknown, 0 free, 1..100 occupied) become the loader's map values (0 unknown, 255 free, 1 occupied), the

@@ -27,6 +27,7 @@ STAGE_ALL, STAGE_GAUSS, STAGE_GRAD, STAGE_SORT, STAGE_REGION = range(5)
 # LSD defaults, LSD/baseFunc.h:64-68
 lsd_sca, lsd_sig, lsd_angThre, lsd_denThre, pseBin = 0.3, 0.6, 22.5, 0.7, 1024
 z_occ_max_dis = 1.0   # LSD/baseFunc.h:60
+rdp_leastPoint, rdp_threLine, rdp_leastDist = 3, 0.08, 0.5   # RDP defaults, LSD/baseFunc.h:70-72
 
 
 class lsd_params(C.Structure):
@@ -44,6 +45,10 @@ LINE_DTYPE = np.dtype([("k", "f8"), ("b", "f8"), ("dx", "f8"), ("dy", "f8"), ("x
 SEED_DTYPE = np.dtype([("order_idx", "i4"), ("x", "i4"), ("y", "i4"), ("num", "i4"), ("outcome", "i4"),
                        ("final_num", "i4"), ("logNFA", "f8")])
 assert LINE_DTYPE.itemsize == 80 == C.sizeof(lsd_line)
+
+
+class lsd_map_param(C.Structure):      # structMapParam, LSD/baseFunc.h:25-31
+    _fields_ = [("oriMapCol", C.c_int), ("oriMapRow", C.c_int), ("mapResol", C.c_double), ("mapOriX", C.c_double), ("mapOriY", C.c_double)]
 
 
 class lsd_position(C.Structure):  # == structPosition, LSD/baseFunc.h:46-50
@@ -113,6 +118,10 @@ def load_library(path=None):
     L.lsd_scan_to_map_match.argtypes = [vp, vp, i, i, vp, i, vp, i, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp]
     L.lsd_enqueue_scan_to_map_match_device.restype = i
     L.lsd_enqueue_scan_to_map_match_device.argtypes = [vp, vp, i, i, vp, vp, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp, vp]
+    L.lsd_feature_scan_batch.restype = i
+    L.lsd_feature_scan_batch.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp]
+    L.lsd_enqueue_feature_scan_batch_device.restype = i
+    L.lsd_enqueue_feature_scan_batch_device.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -125,7 +134,8 @@ EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error
                     "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_debug_set_stamp_budget", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
-                    "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device"]
+                    "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
+                    "lsd_feature_scan_batch", "lsd_enqueue_feature_scan_batch_device"]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -240,6 +250,31 @@ class Context:
                                                float(z_occ), float(max_esti_dist), out.ctypes.data))
         return out
 
+    def feature_scan_batch(self, scans, lens, map_param, region_point_limit=rdp_leastPoint, thre_line=rdp_threLine,
+                           line_dist_thre_m=rdp_leastDist, pts_cap=4096):
+        """lsd_feature_scan_batch: scans float64 [n, stride, 2] = (range, angle), lens int32 [n] finite readings per scan,
+        map_param = (oriMapCol, oriMapRow, mapResol, mapOriX, mapOriY).  Returns a list of dicts like FeatureScan() below."""
+        sc = np.ascontiguousarray(scans, np.float64)
+        n, stride = sc.shape[0], sc.shape[1]
+        ln = np.ascontiguousarray(lens, np.int32)
+        lines = np.zeros((n, 360), LINE_DTYPE); pts = np.zeros((n, pts_cap, 3), np.float64)
+        nl = np.zeros(n, np.int32); npt = np.zeros(n, np.int32); lp = np.zeros((n, 2), np.float64); sz = np.zeros((n, 2), np.int32)
+        mp = lsd_map_param(int(map_param[0]), int(map_param[1]), float(map_param[2]), float(map_param[3]), float(map_param[4]))
+        self._chk(self.L.lsd_feature_scan_batch(self.h, sc.ctypes.data, ln.ctypes.data, n, stride, mp, int(region_point_limit), float(thre_line),
+                                                float(line_dist_thre_m), lines.ctypes.data, nl.ctypes.data, pts.ctypes.data, pts_cap,
+                                                npt.ctypes.data, lp.ctypes.data, sz.ctypes.data))
+        out = []
+        for i in range(n):
+            if npt[i] > pts_cap:
+                raise RuntimeError("scan %d marks %d pixels, more than pts_cap" % (i, npt[i]))
+            p = pts[i, :npt[i]].copy()
+            im = np.zeros((max(int(sz[i, 1]), 0), max(int(sz[i, 0]), 0)), np.uint8)        # FS.lineIm (myRDP.cpp:38, :141)
+            if len(p):
+                im[p[:, 1].astype(int), p[:, 0].astype(int)] = 255
+            out.append(dict(linesInfo=lines[i, :nl[i]].copy(), len_linesInfo=int(nl[i]), scanImPoint=p, lidarPos=(float(lp[i, 0]), float(lp[i, 1])),
+                            lineIm=im))
+        return out
+
     def occupancy_to_map(self, grid_i8):
         """lsd_occupancy_to_map on an int8 [rows, cols] OccupancyGrid; returns the uint8 map."""
         assert grid_i8.dtype == np.int8 and grid_i8.ndim == 2 and grid_i8.flags.c_contiguous
@@ -307,13 +342,18 @@ class Context:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
             v = get(what, np.int64, 32)
-            return dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
+            d = dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                              "rrr_oob_reads", "cycles_rrr", "cycles_total", "cycles_grow", "cycles_rect",
                              "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "resweep_batches",
-                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_idle", "cycles_select", "cycles_commit",
+                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "nfa_min_abs_enc",
+                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "nfa_min_gap_enc", "cycles_select", "cycles_commit",
                              "filter_skips"),
                             [int(x) for x in v]))
+            # smallest |logNFA| compared with 0 and smallest non-zero gap between two compared NFA values (inf: none seen)
+            for k in ("nfa_min_abs", "nfa_min_gap"):
+                enc = d.pop(k + "_enc")
+                d[k] = float("inf") if enc == 0 else float(np.array([0x7ff0000000000000 - enc], np.uint64).view(np.float64)[0])
+            return d
         if what == DBG_SEEDS:
             ns = self.fetch(image, DBG_NSEED, shape_wh)
             return get(what, SEED_DTYPE, ns)
@@ -389,6 +429,20 @@ def match_pairs(map_lines, scan_lines):
                 continue
             pairs.append((cm, cs))
     return np.array(pairs, np.int32).reshape(-1, 2)
+
+
+def FeatureScan(mapParam, lidarPointPolar, RegionPointLimitNumber=rdp_leastPoint, threLine=rdp_threLine, lineDistThreM=rdp_leastDist, ctx=None):
+    """myrdp::FeatureScan (LSD/myRDP.cpp:9) for one scan: mapParam = (oriMapCol, oriMapRow, mapResol, mapOriX, mapOriY), lidarPointPolar float64
+    [len_lp, 2] = (range, angle) of the finite readings (the caller's read loop drops the infinite ones, LSD/main_on_windows.cpp:115-121).
+    Returns dict(linesInfo, len_linesInfo, scanImPoint [m, 3], lidarPos (x, y), lineIm) -- structFeatureScan (LSD/myRDP.h:55-61)."""
+    own = ctx is None
+    ctx = ctx or Context(0)
+    try:
+        sc = np.ascontiguousarray(lidarPointPolar, np.float64).reshape(1, -1, 2)
+        return ctx.feature_scan_batch(sc, [sc.shape[1]], mapParam, RegionPointLimitNumber, threLine, lineDistThreM)[0]
+    finally:
+        if own:
+            ctx.close()
 
 
 def ScanToMapMatch(mapCache, mapLinesInfo, scanLinesInfo, scanImPoint, lidarPose, lastPose, ctx=None):

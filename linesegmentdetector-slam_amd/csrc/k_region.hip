@@ -104,12 +104,17 @@ struct RCtx {
 
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TRRR, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
-       ST_WAIT, ST_RESWEEP, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TIDLE, ST_TSELECT, ST_TCOMMIT, ST_SKIPPED, ST_COUNT };
+       ST_WAIT, ST_MINNFA, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_MINGAP, ST_TSELECT, ST_TCOMMIT, ST_SKIPPED, ST_COUNT };
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
 //  coincides with a join of wave-uniform control flow makes the compiler treat the uniform loop state as divergent)
 #define STAT(i, v) do { g_stat[c.wave][i] += (unsigned long long)(v); } while (0)
+// ... and two running maxima (every lane the same value): the smallest |logNFA| RectangleImprover has compared with 0, and the
+// smallest non-zero difference between two NFA values it has compared with each other, both kept as kInfBits - bit pattern so
+// that the zero-initialised counters work with max (tests/test_parity_gpu.py::test_nfa_decisions_are_far_from_ties)
+#define STATMAX(i, v) do { const unsigned long long n_ = (v); if (n_ > g_stat[c.wave][i]) g_stat[c.wave][i] = n_; } while (0)
+constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 #ifdef LSD_REGION_STATS
 #define DSTAT(i, v) STAT(i, v)
 #define NOW() ((long long)__builtin_amdgcn_s_memtime())
@@ -1093,6 +1098,8 @@ __device__ __noinline__ double improve(int cw_) {
         }
         if (!eval) continue;
         const double v = rect_nfa(c, r);
+        STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v)));                 // (v is compared with 0: :1075, :242)
+        if (step > 0 && v != bestNFA) STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA)));
         if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
         else if (v > bestNFA) { bestNFA = v; best = r; }
     }
@@ -1668,7 +1675,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 32);
         if (lane == 0 && wave == 0) { g_stat[c.wave][ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][ST_SEEDS] = (unsigned long long)nseeds; }
         if (lane < ST_COUNT) {
-            if (lane == ST_MAXREG) atomicMax(&st[lane], g_stat[c.wave][lane]);
+            if (lane == ST_MAXREG || lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][lane]);
             else atomicAdd(&st[lane], g_stat[c.wave][lane]);
         }
     }

@@ -775,6 +775,66 @@ int lsd_scan_to_map_match(lsd_ctx* c, const double* map_cache, int cols, int row
     return LSD_OK;
 }
 
+int lsd_enqueue_feature_scan_batch_device(lsd_ctx* c, const lsd_polar* d_scans, const int* d_lens, int n_scans, int stride,
+                                          lsd_map_param mp, int region_point_limit, double thre_line, double line_dist_thre_m,
+                                          lsd_line* d_lines_out, int* d_n_lines, lsd_position* d_pts_out, int pts_cap, int* d_n_pts,
+                                          double* d_lidar_pos, int* d_im_size, void* stream) {
+    if (!c || !d_scans || !d_lens || n_scans <= 0 || stride <= 0 || !d_lines_out || !d_n_lines || !d_n_pts || !d_lidar_pos || !d_im_size ||
+        pts_cap < 0 || (pts_cap > 0 && !d_pts_out) || !(mp.mapResol > 0))
+        return LSD_ERR_INVALID;
+    if (stride > rdp_max_len()) return LSD_ERR_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;              // NULL: the default (null) stream, as everywhere in HIP
+    launch_rdp(reinterpret_cast<const double*>(d_scans), d_lens, n_scans, stride, mp.oriMapCol, mp.oriMapRow, mp.mapResol, mp.mapOriX, mp.mapOriY,
+               region_point_limit, thre_line, line_dist_thre_m, d_lines_out, d_n_lines, reinterpret_cast<double*>(d_pts_out), pts_cap, d_n_pts,
+               d_lidar_pos, d_im_size, s);
+    HIPCHK(c, hipGetLastError());
+    c->last_stream = s;
+    return LSD_OK;
+}
+
+int lsd_feature_scan_batch(lsd_ctx* c, const lsd_polar* scans, const int* lens, int n_scans, int stride, lsd_map_param mp,
+                           int region_point_limit, double thre_line, double line_dist_thre_m, lsd_line* lines_out, int* n_lines,
+                           lsd_position* pts_out, int pts_cap, int* n_pts, double* lidar_pos, int* im_size) {
+    if (!c || !scans || !lens || n_scans <= 0 || stride <= 0 || !lines_out || !n_lines || !n_pts || !lidar_pos || !im_size || pts_cap < 0 ||
+        (pts_cap > 0 && !pts_out))
+        return LSD_ERR_INVALID;
+    for (int i = 0; i < n_scans; i++) if (lens[i] < 0 || lens[i] > stride) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t b_sc = (size_t)n_scans * stride * sizeof(lsd_polar), b_len = (size_t)n_scans * sizeof(int);
+    const size_t b_li = (size_t)n_scans * LSD_RDP_MAX_LINES * sizeof(lsd_line), b_pt = (size_t)n_scans * (pts_cap > 0 ? pts_cap : 1) * sizeof(lsd_position);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t total = up(b_sc) + up(b_len) + up(b_li) + up(b_pt) + 4 * up((size_t)n_scans * 16);
+    if (total > c->mt_cap) {                           // (shares the staging buffer of the matching entry point)
+        c->mt_cap = 0;
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->mt_buf, total));
+        c->mt_cap = total;
+    }
+    uint8_t* base = c->mt_buf;
+    lsd_polar* d_sc = reinterpret_cast<lsd_polar*>(base); base += up(b_sc);
+    int* d_len = reinterpret_cast<int*>(base); base += up(b_len);
+    lsd_line* d_li = reinterpret_cast<lsd_line*>(base); base += up(b_li);
+    lsd_position* d_pt = reinterpret_cast<lsd_position*>(base); base += up(b_pt);
+    int* d_nl = reinterpret_cast<int*>(base); base += up((size_t)n_scans * 16);
+    int* d_np = reinterpret_cast<int*>(base); base += up((size_t)n_scans * 16);
+    double* d_lp = reinterpret_cast<double*>(base); base += up((size_t)n_scans * 16);
+    int* d_sz = reinterpret_cast<int*>(base);
+    HIPCHK(c, hipMemcpyAsync(d_sc, scans, b_sc, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_len, lens, b_len, hipMemcpyHostToDevice, c->stream));
+    const int st = lsd_enqueue_feature_scan_batch_device(c, d_sc, d_len, n_scans, stride, mp, region_point_limit, thre_line, line_dist_thre_m,
+                                                         d_li, d_nl, d_pt, pts_cap, d_np, d_lp, d_sz, c->stream);
+    if (st != LSD_OK) return st;
+    HIPCHK(c, hipMemcpyAsync(lines_out, d_li, b_li, hipMemcpyDeviceToHost, c->stream));
+    if (pts_cap > 0) HIPCHK(c, hipMemcpyAsync(pts_out, d_pt, (size_t)n_scans * pts_cap * sizeof(lsd_position), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(n_lines, d_nl, b_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(n_pts, d_np, b_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(lidar_pos, d_lp, (size_t)n_scans * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(im_size, d_sz, (size_t)n_scans * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LSD_OK;
+}
+
 int lsd_debug_calibrate(lsd_ctx* c, size_t bytes) {
     if (!c || bytes < 8) return LSD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));

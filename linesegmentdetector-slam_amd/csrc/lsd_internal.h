@@ -107,6 +107,10 @@ void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_compact_lines(const lsd_line* lines, const int32_t* counts, int max_lines, int n, lsd_line* flat, int32_t* offsets, hipStream_t s);
+void launch_rdp(const double* scans, const int* lens, int n, int stride, int oriMapCol, int oriMapRow, double mapResol, double mapOriX,
+                double mapOriY, int region_point_limit, double thre_line, double line_dist_thre_m, lsd_line* lines_out, int* n_lines,
+                double* pts_out, int pts_cap, int* n_pts, double* lidar_pos, int* im_size, hipStream_t s);
+int rdp_max_len();
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 
 // x86-64 cvttsd2si semantics of the reference's (int) casts: NaN, +-inf and

@@ -828,3 +828,145 @@ int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
     }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------ */
+/* myrdp::FeatureScan, LSD/myRDP.cpp (see lsd_oracle.h)                                  */
+/* ------------------------------------------------------------------------------------ */
+static double rdp_thre_delta(double val)                                  /* getThresholdDeltaDist :391-412 */
+{
+    if (val <= 0.3) return 0.02;
+    if (val <= 0.5) return 0.05;
+    if (val <= 0.8) return 0.11;
+    if (val <= 1) return 0.17;
+    if (val <= 2) return 0.6;
+    if (val <= 3) return 0.7;
+    if (val <= 4) return 0.85;
+    if (val <= 5) return 0.9;
+    if (val <= 6) return 1;
+    return 1.1;
+}
+
+static void rdp_split(const orc_polar *sc, const double *px, const double *py, unsigned char *split, int len_lp, int sp, int ep,
+                      double threLine)                                    /* SplitMergeAssistant :223-302 */
+{
+    const int len = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;         /* :228-243 (the cluster may wrap around the scan) */
+    if (len <= 2) return;
+    const double k = (py[ep] - py[sp]) / (px[ep] - px[sp]);               /* :249 */
+    const double d = py[ep] - k * px[ep];
+    double dist_max = 0;
+    int i_max = 0;
+    for (int i = 1; i < len - 1; i++) {
+        int a = sp + i;
+        if (a >= len_lp) a -= len_lp;
+        const double dist = fabs(k * px[a] - py[a] + d) / sqrt(pow(k, 2) + 1);   /* :256 */
+        if (dist > dist_max) { dist_max = dist; i_max = a; }
+    }
+    const double threDist = sc[i_max].range > 9 ? sc[i_max].range * threLine : threLine;   /* :263-267 */
+    if (dist_max > threDist) {
+        rdp_split(sc, px, py, split, len_lp, sp, i_max, threLine);
+        rdp_split(sc, px, py, split, len_lp, i_max, ep, threLine);
+        split[i_max] = 1;
+    }
+}
+
+int orc_feature_scan(orc_map_param mp, const orc_polar *scan, int len_lp, int region_point_limit, double thre_line,
+                     double line_dist_thre_m, orc_line *lines_out, int *n_lines, orc_position *pts_out, int pts_cap, int *n_pts,
+                     double *lidar_pos, int *im_size)
+{
+    if (!scan || len_lp < 1 || !lines_out || !n_lines || !n_pts || !lidar_pos || !im_size || (pts_cap > 0 && !pts_out)) return -1;
+    double *px = (double *)malloc(sizeof(double) * (size_t)len_lp * 2), *py = px + len_lp;
+    unsigned char *split = (unsigned char *)calloc((size_t)len_lp, 1);
+    int *cs = (int *)malloc(sizeof(int) * (size_t)len_lp * 2), *ce = cs + len_lp;
+    int *axis = (int *)malloc(sizeof(int) * ((size_t)len_lp + 2));
+    if (!px || !split || !cs || !axis) { free(px); free(split); free(cs); free(axis); return -3; }
+    /* scanPose = {0, 0, 0} (:11) */
+    for (int i = 0; i < len_lp; i++) { px[i] = scan[i].range * cos(scan[i].angle + 0.0) + 0.0; py[i] = scan[i].range * sin(scan[i].angle + 0.0) + 0.0; }
+    /* RegionSegmentation :304-389 */
+    int cellNumber = 0, startNum = 0;
+    for (int i = 0; i < len_lp; i++) {
+        const int nx = i == len_lp - 1 ? 0 : i + 1;
+        const double dX = px[i] - px[nx], dY = py[i] - py[nx];
+        const double deltaDist = sqrt(dX * dX + dY * dY);
+        const double thre = rdp_thre_delta(scan[i].range);
+        if (deltaDist > thre) {
+            cs[cellNumber] = startNum; ce[cellNumber] = i;                 /* :346-351 */
+            if (abs(i - startNum) >= region_point_limit) cellNumber++;
+            startNum = i + 1;                                              /* :354-358 (the point itself is never used) */
+        }
+        if (deltaDist <= thre && i == len_lp - 1) cs[0] = startNum;        /* :361-365 the last cluster joins the first */
+    }
+    /* SplitMerge :187-221 */
+    for (int c = 0; c < cellNumber; c++) rdp_split(scan, px, py, split, len_lp, cs[c], ce[c], thre_line);
+    /* pixel coordinates and the image size :16-37 */
+    double minX = INFINITY, minY = INFINITY, maxX = 0, maxY = 0;
+    double *gx = px, *gy = py;                                             /* (the metric coordinates are not needed any more) */
+    for (int i = 0; i < len_lp; i++) {
+        const double X = floor((scan[i].range * cos(scan[i].angle + 0.0) + 0.0 - mp.mapOriX) / mp.mapResol);
+        const double Y = floor((scan[i].range * sin(scan[i].angle + 0.0) + 0.0 - mp.mapOriY) / mp.mapResol);
+        gx[i] = X; gy[i] = Y;
+        if (X < minX) minX = X;
+        if (X > maxX) maxX = X;
+        if (Y < minY) minY = Y;
+        if (Y > maxY) maxY = Y;
+    }
+    const int oriXLim = cvt_int(ceil(maxX - minX)), oriYLim = cvt_int(ceil(maxY - minY));
+    lidar_pos[0] = floor((0.0 - mp.mapOriX) / mp.mapResol - minX);
+    lidar_pos[1] = floor((0.0 - mp.mapOriY) / mp.mapResol - minY);
+    im_size[0] = oriXLim; im_size[1] = oriYLim;
+    const double lineDistThre = line_dist_thre_m / mp.mapResol;
+    int nl = 0, np = 0;
+    for (int c = 0; c < cellNumber; c++) {                                 /* :45-177 */
+        const int sp = cs[c], ep = ce[c];
+        const int len_axis = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;
+        int num_split = 1;
+        for (int j = 0; j < len_axis; j++) {
+            int v = sp + j;
+            if (v >= len_lp) v -= len_lp;
+            if (split[v]) axis[num_split++] = v;
+        }
+        axis[0] = sp;
+        axis[num_split++] = ep;
+        for (int j = 0; j < num_split - 1; j++) {
+            const double ax = gx[axis[j]], ay = gy[axis[j]], bx = gx[axis[j + 1]], by = gy[axis[j + 1]];
+            const double lineDist = sqrt(pow(ax - bx, 2) + pow(ay - by, 2));
+            if (!(lineDist >= lineDistThre)) continue;
+            const double x1 = ax - minX, y1 = ay - minY, x2 = bx - minX, y2 = by - minY;
+            const double k = (y2 - y1) / (x2 - x1);
+            double ang = orc_atand(k);
+            int orient = 1;
+            if (ang < 0) { ang += 180; orient = -1; }
+            const int xLow = cvt_int(floor(x1 > x2 ? x2 : x1)), xHigh = cvt_int(ceil(x1 > x2 ? x1 : x2));
+            const int yLow = cvt_int(floor(y1 > y2 ? y2 : y1)), yHigh = cvt_int(ceil(y1 > y2 ? y1 : y2));
+            const double xRang = fabs(x2 - x1), yRang = fabs(y2 - y1);
+            const int xx_len = xHigh - xLow + 1, yy_len = yHigh - yLow + 1;
+            /* the reference sizes its arrays by xRang > yRang and walks them by xx_len > yy_len (:109-153); the coordinates are
+             * integers, so the two tests agree; the sampled length is walked here */
+            const int along_x = xRang > yRang;
+            const int cnt = along_x ? xx_len : yy_len;
+            for (int m = 0; m < cnt; m++) {
+                int xx, yy;
+                if (along_x) { xx = m + xLow; yy = cvt_int(round((xx - x1) * k + y1)); }
+                else { yy = m + yLow; xx = cvt_int(round((yy - y1) / k + x1)); }
+                if (xx < 0 || xx >= oriXLim || yy < 0 || yy >= oriYLim) { xx = 0; yy = 0; }
+                if (xx != 0 && yy != 0) {                                  /* 0 doubles as "invalid" (:140, :151) */
+                    if (np < pts_cap) { pts_out[np].x = xx; pts_out[np].y = yy; pts_out[np].ang = 0; }
+                    np++;
+                }
+            }
+            if (nl < 360) {
+                orc_line *L = &lines_out[nl];
+                memset(L, 0, sizeof(*L));
+                L->k = k; L->b = (y1 + y2) / 2.0 - k * (x1 + x2) / 2.0;
+                L->dx = orc_cosd(ang); L->dy = orc_sind(ang);
+                L->x1 = x1; L->y1 = y1; L->x2 = x2; L->y2 = y2;
+                L->len = sqrt(pow(y2 - y1, 2) + pow(x2 - x1, 2));
+                L->orient = orient;
+            }
+            nl++;
+        }
+    }
+    *n_lines = nl; *n_pts = np;
+    free(px); free(split); free(cs); free(axis);
+    return 0;
+}

@@ -93,4 +93,21 @@ int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- myrdp::FeatureScan (LSD/myRDP.cpp:9-185 with RegionSegmentation :304-389, SplitMerge :187-221, SplitMergeAssistant
+ * :223-302, getThresholdDeltaDist :391-412): clusters one lidar scan, splits the clusters by Ramer-Douglas-Peucker and turns the
+ * chords of at least lineDistThreM metres into line records + the pixels of their raster.  SURVEY 8f #4.
+ * PARITY: pinned only loosely -- data/ScanlinesInfo.txt holds the MATLAB prototype's 11 lines for one frame of data/Lidar.txt
+ * (tests/test_oracle.py::test_feature_scan_against_the_matlab_golden); the reference cannot be built here.
+ * The reference reads one element past its point array when the last reading closes a cluster (:354-358); the value is never
+ * used, so the restatement does not read it.  A vertical chord makes its slope infinite (:245): IEEE arithmetic then gives NaN
+ * distances and no split, which is restated as it is. */
+typedef struct { double range, angle; } orc_polar;                 /* structLidarPointPolar (myRDP.h:34-38) without its work flag */
+typedef struct { int oriMapCol, oriMapRow; double mapResol, mapOriX, mapOriY; } orc_map_param;   /* structMapParam, baseFunc.h:25-31 */
+/* lines_out[360], pts_out[pts_cap] (x, y, 0): returns 0 and sets *n_lines, *n_pts (the number of raster pixels; only the first
+ * pts_cap are stored), lidar_pos[2], im_size[2] = (oriXLim, oriYLim). */
+int orc_feature_scan(orc_map_param mp, const orc_polar *scan, int len_lp, int region_point_limit, double thre_line,
+                     double line_dist_thre_m, orc_line *lines_out, int *n_lines, orc_position *pts_out, int pts_cap, int *n_pts,
+                     double *lidar_pos, int *im_size);
+
 #endif

@@ -192,3 +192,37 @@ def scan_to_map_match(map_cache, map_lines, scan_lines, scan_im_points, lidar_po
     if rc != 0:
         raise RuntimeError("orc_scan_to_map_match failed: %d" % rc)
     return out
+
+
+class _Polar(C.Structure):
+    _fields_ = [("range", C.c_double), ("angle", C.c_double)]
+
+
+class _MapParam(C.Structure):
+    _fields_ = [("oriMapCol", C.c_int), ("oriMapRow", C.c_int), ("mapResol", C.c_double), ("mapOriX", C.c_double), ("mapOriY", C.c_double)]
+
+
+def feature_scan(scan, map_param, region_point_limit=3, thre_line=0.08, line_dist_thre_m=0.5, pts_cap=8192, _lib=None):
+    """Oracle for myrdp::FeatureScan (LSD/myRDP.cpp:9-185) on ONE scan: scan float64 [len_lp, 2] = (range, angle) of the finite
+    readings, map_param = (oriMapCol, oriMapRow, mapResol, mapOriX, mapOriY); defaults = baseFunc.h:70-72.
+    Returns dict(lines LINE_DTYPE[n], pts float64 [m, 3], lidar_pos (x, y), im_size (oriXLim, oriYLim), lineIm uint8 [oriYLim, oriXLim])."""
+    L = _lib or lib()
+    L.orc_feature_scan.restype = C.c_int
+    L.orc_feature_scan.argtypes = [_MapParam, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int),
+                                   C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    sc = np.ascontiguousarray(scan, np.float64).reshape(-1, 2)
+    lines = np.zeros(360, LINE_DTYPE)
+    pts = np.zeros((pts_cap, 3), np.float64)
+    nl, npts = C.c_int(0), C.c_int(0)
+    lidar = np.zeros(2, np.float64); size = np.zeros(2, np.int32)
+    mp = _MapParam(int(map_param[0]), int(map_param[1]), float(map_param[2]), float(map_param[3]), float(map_param[4]))
+    rc = L.orc_feature_scan(mp, sc.ctypes.data, len(sc), region_point_limit, thre_line, line_dist_thre_m, lines.ctypes.data, C.byref(nl),
+                            pts.ctypes.data, pts_cap, C.byref(npts), lidar.ctypes.data, size.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_feature_scan failed: %d" % rc)
+    assert npts.value <= pts_cap and nl.value <= 360
+    pts = pts[:npts.value].copy()
+    im = np.zeros((max(int(size[1]), 0), max(int(size[0]), 0)), np.uint8)
+    if len(pts):
+        im[pts[:, 1].astype(int), pts[:, 0].astype(int)] = 255
+    return dict(lines=lines[:nl.value].copy(), pts=pts, lidar_pos=(float(lidar[0]), float(lidar[1])), im_size=(int(size[0]), int(size[1])), lineIm=im)

@@ -58,6 +58,16 @@ def main():
     ys, xs = np.nonzero(im)
     out["matlab_MaplineIm_lit_yx"] = np.stack([ys, xs], 1).astype(np.int32)
     np.savez_compressed(OUT, **out)
+    # the lidar log and the MATLAB prototype's scan lines (data/Lidar.txt: 99 frames x 360 (range, angle) readings, inf = no return;
+    # data/ScanlinesInfo.txt / ScanlineIm.txt: its 12 lines and raster for frame 31 of that log, found by trying every frame)
+    lid = np.loadtxt(os.path.join(REF, "data/Lidar.txt")).reshape(-1, 360, 2)
+    sl = np.loadtxt(os.path.join(REF, "data/ScanlinesInfo.txt"))
+    sim = np.loadtxt(os.path.join(REF, "data/ScanlineIm.txt"))
+    assert lid.shape == (99, 360, 2) and sl.shape == (12, 9) and sim.shape == (237, 832)
+    ys, xs = np.nonzero(sim)
+    np.savez_compressed(os.path.join(os.path.dirname(OUT), "lidar.npz"), lidar=lid.astype(np.float64), matlab_ScanlinesInfo=sl,
+                        matlab_ScanlineIm_lit_yx=np.stack([ys, xs], 1).astype(np.int32), matlab_ScanlineIm_shape=np.array(sim.shape, np.int32),
+                        matlab_frame=np.int32(31))
     json.dump(meta, open(os.path.join(os.path.dirname(OUT), "maps_meta.json"), "w"), indent=1)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

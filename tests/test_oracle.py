@@ -268,3 +268,62 @@ def test_scan_to_map_match_without_scan_points_is_rejected(maps, oracle):
     ln["x1"], ln["y1"], ln["x2"], ln["y2"] = 5, 5, 30, 5
     out = oracle.scan_to_map_match(mc, ln, ln, np.zeros((0, 3)), (10.0, 10.0, 0.0), (-1.0, -1.0, 0.0), np.array([[0, 0]], np.int32))
     assert out.shape == (1, 4, 4) and np.all(np.isinf(out[0, :, 3])) and np.all(np.isfinite(out[0, :, :3]))
+
+
+# ---- myrdp::FeatureScan --------------------------------------------------------------------------
+RDP_MAP_PARAM = (1377, 428, 0.025, -4.43187, -5.49357)          # data/mapParam.txt (the map the lidar log belongs to)
+
+
+def rdp_golden_check(res, z):
+    """(lines of data/ScanlinesInfo.txt reproduced exactly, its raster pixels hit) for a FeatureScan result of the golden's frame."""
+    gold = z["matlab_ScanlinesInfo"]
+    L = res["lines"] if "lines" in res else res["linesInfo"]
+    ours = np.stack([L[k] for k in ("k", "b", "dx", "dy", "x1", "y1", "x2", "y2", "len")], 1)
+    matched = 0
+    for row in gold:
+        for o in ours:
+            if np.array_equal(o[4:8], row[4:8]) and np.allclose(o, row, rtol=1e-13, atol=1e-13):
+                matched += 1
+                break
+    im = res["lineIm"] > 0
+    hits = 0
+    for y, x in z["matlab_ScanlineIm_lit_yx"]:                   # the prototype's raster sits at (-1, -1) of the C++ coordinates
+        if y + 1 < im.shape[0] and x + 1 < im.shape[1] and im[y + 1, x + 1]:
+            hits += 1
+    return matched, hits
+
+
+def test_feature_scan_against_the_matlab_golden(oracle):
+    """The only outputs the reference holds for FeatureScan: data/ScanlinesInfo.txt (12 lines) and data/ScanlineIm.txt (1003 lit
+    pixels of a 237 x 832 raster) of the MATLAB prototype, for frame 31 of data/Lidar.txt (found by trying every frame: the only
+    one that gives a 832 x 237 image).  The restatement yields 12 lines too; 8 of the golden 12 are reproduced with identical
+    integer end points and k, b, dx, dy, len to 13 digits; the other four are the bottom wall, which the prototype splits at
+    three more points (and it does not have two short segments the C++ code finds).  A loose pin, like the LSD one."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lidar.npz"))
+    sc = z["lidar"][int(z["matlab_frame"])]
+    sc = sc[np.isfinite(sc[:, 0])]
+    assert len(sc) == 326
+    res = oracle.feature_scan(sc, RDP_MAP_PARAM)
+    assert len(res["lines"]) == 12 and res["im_size"] == (832, 237) and tuple(z["matlab_ScanlineIm_shape"]) == (237, 832)
+    matched, hits = rdp_golden_check(res, z)
+    assert matched == 8
+    assert hits >= 700                                            # measured: 711 of 1003
+
+
+def test_feature_scan_on_the_whole_lidar_log(oracle):
+    """Every frame of data/Lidar.txt: the raster pixels lie inside the image and off row / column 0 (the reference's "invalid" mark),
+    the line count stays below the reference's 360 records, end points are integers inside the image."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lidar.npz"))
+    total = 0
+    for f in range(len(z["lidar"])):
+        sc = z["lidar"][f]
+        sc = sc[np.isfinite(sc[:, 0])]
+        res = oracle.feature_scan(sc, RDP_MAP_PARAM)
+        w, h = res["im_size"]
+        p = res["pts"]
+        assert len(res["lines"]) < 360 and len(p) > 0
+        assert p[:, 0].min() >= 1 and p[:, 0].max() < w and p[:, 1].min() >= 1 and p[:, 1].max() < h
+        for k in ("x1", "y1", "x2", "y2"):
+            assert np.array_equal(res["lines"][k], np.round(res["lines"][k]))
+        total += len(res["lines"])
+    assert total > 900

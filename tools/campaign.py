@@ -33,6 +33,7 @@ def synth(rng):
 
 
 bad = 0
+nfa_abs, nfa_gap = float('inf'), float('inf')      # closest any NFA decision of the campaign came to a tie
 t0 = time.time()
 for i in (only or range(n_img)):
     rng = np.random.default_rng(10_000 + i)
@@ -46,6 +47,8 @@ for i in (only or range(n_img)):
     d = ref["dbg"]
     lines, im = ctx.run(img.copy(), lsd.make_params(**kw) if kw else None)
     used = (ctx.fetch(0, lsd.DBG_STATE, (d["w"], d["h"])) & 3).astype(np.uint8)
+    st_ = ctx.fetch(0, lsd.DBG_STATS, (d["w"], d["h"]))
+    nfa_abs, nfa_gap = min(nfa_abs, st_["nfa_min_abs"]), min(nfa_gap, st_["nfa_min_gap"])
     ok = len(lines) == len(ref["lines"]) and np.array_equal(used, d["used"]) and np.array_equal(im, ref["lineIm"])
     if ok and len(lines):
         ok = all(np.abs(lines[f] - ref["lines"][f]).max() < 1e-6 for f in ("x1", "y1", "x2", "y2")) and np.array_equal(lines["orient"], ref["lines"]["orient"])
@@ -59,4 +62,4 @@ for i in (only or range(n_img)):
               "| equals the correctly rounded restatement:", eq, flush=True)
         if not eq:
             np.save(os.path.join(ROOT, "gpurun_out", "campaign_bad_%d.npy" % i), img)
-print("campaign: %d images, %d mismatches, %.0f s" % (n_img, bad, time.time() - t0))
+print("campaign: %d images, %d mismatches, %.0f s; smallest |logNFA| compared with 0: %.3g, smallest non-zero gap between compared NFA values: %.3g" % (n_img, bad, time.time() - t0, nfa_abs, nfa_gap))

@@ -22,6 +22,12 @@ def per_kernel(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+def source_sha():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.source_sha()
+
+
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")
@@ -32,7 +38,7 @@ def main():
            "--no-cpu-baseline` (512 x 2048^2); counters are KB per dispatch, averaged over the launches of each kernel; "
            "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (confirmed for 8-B-per-lane loads with "
            "tools/pmc_calib.py: profiles/r01b_pmc_calib_*.csv)",
-           "build": build, "kernels": {}}
+           "build": build, "source_sha": source_sha(), "kernels": {}}
     for k in KERNELS:
         if k in f and k in w:
             res["kernels"][k] = {"FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w[k], "launches": [nf[k], nw[k]],
