@@ -118,10 +118,11 @@ def load_library(path=None):
     L.lsd_scan_to_map_match.argtypes = [vp, vp, i, i, vp, i, vp, i, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp]
     L.lsd_enqueue_scan_to_map_match_device.restype = i
     L.lsd_enqueue_scan_to_map_match_device.argtypes = [vp, vp, i, i, vp, vp, vp, i, lsd_position, lsd_position, vp, i, dbl, dbl, vp, vp]
-    L.lsd_feature_scan_batch.restype = i
-    L.lsd_feature_scan_batch.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp]
-    L.lsd_enqueue_feature_scan_batch_device.restype = i
-    L.lsd_enqueue_feature_scan_batch_device.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp, vp]
+    if hasattr(L, "lsd_feature_scan_batch") or not os.environ.get("LSD_HIP_LIB"):      # (a developer A/B build may predate this entry point)
+        L.lsd_feature_scan_batch.restype = i
+        L.lsd_feature_scan_batch.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp]
+        L.lsd_enqueue_feature_scan_batch_device.restype = i
+        L.lsd_enqueue_feature_scan_batch_device.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -341,14 +342,15 @@ class Context:
         if what == DBG_ORDER_VAL:
             return get(what, np.uint16, npx)[:self.fetch(image, DBG_NB, shape_wh)]
         if what == DBG_STATS:
-            v = get(what, np.int64, 32)
+            v = get(what, np.int64, 48)
             d = dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                             "rrr_oob_reads", "cycles_rrr", "cycles_total", "cycles_grow", "cycles_rect",
-                             "cycles_nfa", "cycles_mark", "max_region", "nfa_px", "seeds", "exact_angle_evals",
-                             "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "nfa_min_abs_enc",
-                             "slow_batches", "cycles_eval", "cycles_sums", "cycles_refine", "nfa_min_gap_enc", "cycles_select", "cycles_commit",
-                             "filter_skips"),
-                            [int(x) for x in v]))
+                          "rrr_oob_reads", "cycles_refill", "cycles_total", "cycles_grow", "cycles_rect",
+                          "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
+                          "wait_ring", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
+                          "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
+                          "wait_noseed", "depth_ups", "depth_downs", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "x5", "x6", "x7",
+                          "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
+                         [int(x) for x in v]))
             # smallest |logNFA| compared with 0 and smallest non-zero gap between two compared NFA values (inf: none seen)
             for k in ("nfa_min_abs", "nfa_min_gap"):
                 enc = d.pop(k + "_enc")

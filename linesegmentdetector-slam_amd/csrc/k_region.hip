@@ -57,6 +57,9 @@ namespace RVAR {
 #ifndef LSD_REGION_WAIT_SLEEP
 #define LSD_REGION_WAIT_SLEEP 127      // x 64 clocks
 #endif
+#ifndef LSD_REGION_WATCHDOG
+#define LSD_REGION_WATCHDOG 600000     // sleeps of LSD_REGION_WAIT_SLEEP x 64 clocks (~3.4 us each) with the cursor standing still
+#endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
 constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
@@ -88,6 +91,7 @@ struct RCtx {
     const double* deg;
     uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
     uint32_t* epochmap;
+    uint32_t* tep;       // per 8x8-pixel tile: epoch + 1 of the latest accepted line with a pixel in it (0: none)
     uint32_t* stamp;     // this wave's curMap stamps
     uint32_t* spill;
     uint32_t* gcopy;
@@ -102,18 +106,30 @@ struct RCtx {
     const double* ptab;
 };
 
-enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TRRR, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
-       ST_TMARK, ST_MAXREG, ST_NFAPX, ST_SEEDS, ST_EXACT, ST_TILEFETCH, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
-       ST_WAIT, ST_MINNFA, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_MINGAP, ST_TSELECT, ST_TCOMMIT, ST_SKIPPED, ST_COUNT };
+enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
+       ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
+       ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_X5, ST_X6, ST_X7, ST_COUNT };
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
 //  coincides with a join of wave-uniform control flow makes the compiler treat the uniform loop state as divergent)
-#define STAT(i, v) do { g_stat[c.wave][i] += (unsigned long long)(v); } while (0)
+#ifdef LSD_REGION_STATS
+constexpr int kStatSlots = ST_COUNT;
+__device__ constexpr int sslot(int i) { return i; }
+#else
+// the product build keeps the always-on counters only (LDS is the scarce resource of this kernel)
+constexpr int kStatSlots = 14;
+__device__ constexpr int sslot(int i) {
+    return i == ST_GROW ? 0 : i == ST_GROWN ? 1 : i == ST_NFA ? 2 : i == ST_RRR ? 3 : i == ST_RRRPASS ? 4 : i == ST_SENT ? 5 : i == ST_OOB ? 6 :
+           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : 11;
+}
+#endif
+#define STAT(i, v) do { g_stat[c.wave][sslot(i)] += (unsigned long long)(v); } while (0)
 // ... and two running maxima (every lane the same value): the smallest |logNFA| RectangleImprover has compared with 0, and the
 // smallest non-zero difference between two NFA values it has compared with each other, both kept as kInfBits - bit pattern so
 // that the zero-initialised counters work with max (tests/test_parity_gpu.py::test_nfa_decisions_are_far_from_ties)
-#define STATMAX(i, v) do { const unsigned long long n_ = (v); if (n_ > g_stat[c.wave][i]) g_stat[c.wave][i] = n_; } while (0)
+#define STATMAX(i, v) do { const unsigned long long n_ = (v); if (n_ > g_stat[c.wave][sslot(i)]) g_stat[c.wave][sslot(i)] = n_; } while (0)
 constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 #ifdef LSD_REGION_STATS
 #define DSTAT(i, v) STAT(i, v)
@@ -127,10 +143,9 @@ constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 // as LDS (ds_ instructions) instead of through generic pointers carried in the context (flat_ instructions).
 __shared__ uint32_t g_lst[NW][LCAP];                      // region list (packed y<<16 | x), grow order
 __shared__ uint16_t g_wl[NW][2][LCAP + 2];                // sweep worklists (+ a dummy slot for predicated stores)
-__shared__ uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
+__shared__ __attribute__((aligned(16))) uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
 __shared__ int g_ttag[NW][NT];
-__shared__ int g_sincl[NW][64], g_slo[NW][64], g_sx[NW][64];
-__shared__ unsigned long long g_stat[NW][ST_COUNT];      // per-wave counters (see ST_* above); kept out of registers
+__shared__ unsigned long long g_stat[NW][kStatSlots];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
 __shared__ RCtx g_ctx[NW];                                // the wave's context: the out-of-line stages get the wave number and read it here
                                                           // (a struct passed by value travels through scratch memory at every call)
@@ -159,6 +174,9 @@ __device__ __forceinline__ double acc32(int wave, int lane, int cnt, double S) {
 }
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// a load that does not stop at the CU's vector cache: for words other wavefronts change with ATOMICS (performed in L2, they leave a
+// stale line in the L1 behind; plain stores of the same CU do not)
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
 // Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
@@ -243,7 +261,6 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
     }
     [[maybe_unused]] const long long tt0 = NOW();
     if (__builtin_amdgcn_readfirstlane(g_ws[wave].dirty)) { wg_fence(); g_ws[wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
-    DSTAT(ST_TILEFETCH, 1);
     const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[wave].cur_id);
     AS1 const uint32_t* const pw = uglobal(c.pw);
     AS1 const uint32_t* const stamp = uglobal(c.stamp);
@@ -536,7 +553,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
             }
             if (!bulk) {
                 // ---- pixel by pixel, in reference order (lane order) ----
-                DSTAT(ST_SLOW, 1);
                 unsigned long long todo = candm;
                 while (todo) {
                     int l, decided = -1;                 // 1 take, 0 reject, -1 exact test needed
@@ -682,7 +698,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         filter = filter && room;
                         nxt_cnt += room ? nskip : 0;
                         wi += nskip;
-                        DSTAT(ST_SKIPPED, nskip);
                         continue;
                     }
                     // the run of consecutive entries to test (no skipped entry in between: its check would be stale after an accept)
@@ -820,7 +835,6 @@ __device__ __noinline__ int radius_reduce(int cw_, int sx, int sy, int num, doub
     c.lane = (int)(threadIdx.x & 63u);
     [[maybe_unused]] const long long t0 = NOW();
     const int r = radius_reduce_impl(c.wave, sx, sy, num, regdeg, denThre);
-    DSTAT(ST_TRRR, NOW() - t0);
     return r;
 }
 __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num, double regdeg, double denThre) {
@@ -988,6 +1002,10 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const double k2 = (vy2 - vy3) / (vx2 - vx3);
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
     int all = 0, ali = 0;
+    // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
+    int* const s_incl = reinterpret_cast<int*>(&g_wl[c.wave][0][0]);
+    int* const s_lo = s_incl + 64;
+    int* const s_x = s_incl + 128;
     for (int cb = 0; cb < xlen; cb += 64) {
         const int i = cb + lane;
         int cntc = 0, lo = 0, xr = 0;
@@ -1011,19 +1029,18 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
         }
         const int tot = __builtin_amdgcn_readlane(inc, 63);
         if (tot == 0) continue;
-        g_sincl[c.wave][lane] = inc; g_slo[c.wave][lane] = lo; g_sx[c.wave][lane] = xr;
+        s_incl[lane] = inc; s_lo[lane] = lo; s_x[lane] = xr;
         all += tot;
-        DSTAT(ST_NFAPX, tot);
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
             bool hit = false;
             if (t < tot) {
                 int ci = 0;                                    // smallest ci with s_incl[ci] > t
                 for (int step = 32; step >= 1; step >>= 1)
-                    if (g_sincl[c.wave][ci + step - 1] <= t) ci += step;
-                const int ex = ci ? g_sincl[c.wave][ci - 1] : 0;
-                const int j = g_slo[c.wave][ci] + (t - ex);
-                const double dv = c.deg[(size_t)j * xLim + g_sx[c.wave][ci]];
+                    if (s_incl[ci + step - 1] <= t) ci += step;
+                const int ex = ci ? s_incl[ci - 1] : 0;
+                const int j = s_lo[ci] + (t - ex);
+                const double dv = c.deg[(size_t)j * xLim + s_x[ci]];
                 hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
             }
             ali += __builtin_popcountll(ballot64(hit));
@@ -1175,7 +1192,7 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
         const size_t q = (size_t)y * w + x;
         if (src || c.stamp[q] == cur_id) {        // curMap == 1 only (src: a stashed list holds exactly those)
             const uint32_t old = c.pw[q];
-            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; }
+            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1); }
             else c.pw[q] = (old & ~3u) | kPwRejected;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
@@ -1211,29 +1228,59 @@ __device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __AT
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Commit ring: one record per seed in flight (index = seed number & (RW-1)).
-//   R_EMPTY  not evaluated yet
-//   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (lref);
-//            whoever moves the cursor over it validates and commits it
+//   R_EMPTY  reserved by a wave (part of its chunk of seeds), not classified yet
 //   R_SKIP   the seed pixel was already used when it was looked at (monotone, so final): nothing to do
-//   R_LIGHT  evaluated, no marks to make (small region :228 or refine failed :237); whoever advances the
-//            cursor checks that no line accepted since the record's snapshot touches what it examined
+//   R_LIGHT  a small region (:228, nothing to mark) grown by the small-region grower: aux = box of what it examined,
+//            relative to the seed; whoever advances the cursor checks that no line accepted since the snapshot touches it
+//   R_LIGHTL a full evaluation without marks (small region :228 or refine failed :237): aux = result slot (box and list
+//            sizes in the slot table, the lists in the slot); checked like R_LIGHT, by the pixels themselves if the box is hit
+//   R_BIG    the small-region grower gave the seed up (its region reaches regThre pixels, leaves the seed's window, or a
+//            test was too close to call): waits for a full evaluation by any wave
+//   R_EVAL   being evaluated in full, ahead of the cursor
+//   R_STASH  evaluated with a result that marks usedMap: record and pixel list wait in the owner's result slot (aux);
+//            whoever moves the cursor over it validates and commits it
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
-//   R_BUSY   being re-evaluated at the cursor
-enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5 };
-constexpr int RW = NW == 4 ? 128 : 256;   // records in flight (> NW * NS + run-ahead over skipped seeds)
+//   R_BUSY   being evaluated at the cursor
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8 };
+constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
+constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
+constexpr int kDepthUp = 32, kDepthDown = 96;   // steps of the adaptive look-ahead (see the seed loop)
+
+constexpr int SCAP = 16;                  // list entries of a small-region group
 
 struct Ring {
-    int state[RW];
-    int snap[RW];
-    short box[RW][4];
-    uint32_t lref[RW];   // list slot of the region (wave * NS + slot), ~0u: no lists kept (box check only)
-    uint32_t lcnt[RW];   // n1 | n2 << 16: sizes of the two lists in the slot (first grow, Refiner's regrow)
+    alignas(4) uint8_t state[RW];
+    uint16_t snap[RW];   // accept epoch (mod 2^16) the result was computed against
+    uint32_t aux[RW];    // see above
 };
+struct SlotTab {         // per result slot (wave * NS + slot) of a full evaluation published as R_LIGHTL
+    short box[NW * NS][4];
+    uint32_t lcnt[NW * NS];   // n1 + 1 | n2 << 16 (n1 + 1 == 0: the lists were not kept, box check only)
+};
+__device__ __forceinline__ int st_ld(uint8_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_st(uint8_t* p, int v) { __hip_atomic_store(p, (uint8_t)v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// compare-and-swap of ONE state byte (call it from one lane): the containing word is swapped, and the swap is retried as long
+// as only the other three bytes of the word have changed in between
+__device__ __forceinline__ bool st_cas(uint8_t* base, int idx, int expect, int desired) {
+    uint32_t* const wp = reinterpret_cast<uint32_t*>(base) + (idx >> 2);
+    const int sh = (idx & 3) * 8;
+    while (true) {
+        const uint32_t oldw = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (((oldw >> sh) & 0xffu) != (uint32_t)expect) return false;
+        const uint32_t neww = (oldw & ~(0xffu << sh)) | ((uint32_t)desired << sh);
+        if (atomicCAS(wp, oldw, neww) == oldw) return true;
+    }
+}
+
+// minimum / maximum over the 8 lanes of a group for small non-negative integers (exact in fp32)
+__device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
+__device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
-    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock;
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
+    __shared__ SlotTab stab;
 
     const size_t img = b.order[blockIdx.x];               // heaviest images first (k_order)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1243,6 +1290,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     RCtx c;
     c.w = w; c.h = h; c.lane = lane; c.wave = wave;
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
+    c.tep = b.tepoch + img * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
     c.sc = b.sc + img * npx;
     c.stamp = b.stamps + (img * NW + wave) * npx;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
@@ -1255,13 +1303,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
     if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
-    if (lane < ST_COUNT) g_stat[c.wave][lane] = 0ull;
+    if (lane < kStatSlots) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
     if (lane < NT) g_ttag[c.wave][lane] = -1;
-    for (int j = threadIdx.x; j < RW; j += 64 * NW) rg.state[j] = R_EMPTY;
+    for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
+    uint32_t* seedpos = b.seedpos + img * npx;
     const int nb = b.nb[img];
     double* recs = b.recs + img * (size_t)b.max_lines * 12;
     double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
@@ -1279,17 +1328,26 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int base = 0; base < nb; base += 64) {
             const int idx = base + lane;
-            const bool ok = idx < nb && (c.pw[ord[idx < nb ? idx : 0]] & 3u) == 0u;   // :222
+            const uint32_t pq = ord[idx < nb ? idx : 0];
+            const bool ok = idx < nb && (c.pw[pq] & 3u) == 0u;   // :222
             const unsigned long long m = ballot64(ok);
-            if (ok) seedidx[cnt + __builtin_popcountll(m & lt)] = (uint32_t)idx;
+            if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; }
         wg_fence();
     }
     __syncthreads();
     const int nseeds = s_nseeds;
 
+    // How far the hand-out and the full evaluations may run ahead of the cursor (s_depth, in seeds).  The further ahead a region is
+    // evaluated, the likelier a line accepted before its turn makes the work void (typical maps: many lines, short evaluations);
+    // but where single evaluations take a millisecond (long sparse structures grown again and again without ever marking
+    // anything) a short look-ahead leaves the other waves without work.  So the depth adapts: it grows while waves find nothing
+    // to do within it, and shrinks when a speculative result is redone or discarded at the cursor.  Ring slots are reused no
+    // sooner than 128 commits later.
+    const int depth_min = min(max(b.tun_soft, 2 * CH), RW - 128), depth_max = min(max(b.tun_claim, depth_min), RW - 128);
+    const int kFeed = min(max(b.tun_feed, 1), 8);           // idle groups that make a wave fetch the windows of its next seeds (a memory round trip)
     // box overlap of record-style boxes against the lines accepted in epochs [snap, now)
     auto hit_since = [&](int snap, int now, int x0, int y0, int x1, int y1) -> bool {
         if (now - snap > RING) return true;
@@ -1304,7 +1362,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (lane == 0) {
             if (trace) {
                 const int oidx = (int)seedidx[k];
-                const uint32_t pp = ord[oidx];
+                const uint32_t pp = seedpos[k];
                 SeedRec tr;
                 tr.order_idx = oidx; tr.x = (int)(pp % (uint32_t)w); tr.y = (int)(pp / (uint32_t)w);
                 tr.num = num0; tr.outcome = outcome; tr.final_num = fnum; tr.logNFA = logNFA;
@@ -1317,6 +1375,20 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     // >= snap: only then can the region's evaluation differ from what it would be now (it read usedMap only as
     // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 in epochmap.
     auto examined_hit = [&](const uint32_t* lp, int cnt, int snap) -> bool {
+        // first by tiles (tep[] is a few KB and stays in the cache): no line accepted since the snapshot has a pixel in any tile
+        // the region's pixels or their neighbours lie in -> nothing examined can have been banned
+        const int tX = c.tilesX;
+        bool thit = false;
+        for (int base = 0; base < cnt; base += 64) {
+            const int k2 = base + lane;
+            if (k2 < cnt) {
+                const uint32_t pkx = lp[k2];
+                const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
+                const int xa = max(x - 1, 0) >> 3, xb = min(x + 1, w - 1) >> 3, ya = max(y - 1, 0) >> 3, yb = min(y + 1, h - 1) >> 3;
+                if ((int)ld_l2(&c.tep[ya * tX + xa]) > snap || (int)ld_l2(&c.tep[ya * tX + xb]) > snap || (int)ld_l2(&c.tep[yb * tX + xa]) > snap || (int)ld_l2(&c.tep[yb * tX + xb]) > snap) thit = true;
+            }
+        }
+        if (!ballot64(thit)) return false;
         bool hit = false;
         for (int base = 0; base < cnt; base += 64) {
             const int k2 = base + lane;
@@ -1334,6 +1406,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
         }
         return ballot64(hit) != 0ull;
+    };
+    // the same question for a box: true if a tile overlapping it holds a pixel of a line accepted in epoch >= snap
+    auto box_tile_hit = [&](int snap, int x0, int y0, int x1, int y1) -> bool {
+        const int tX = c.tilesX;
+        const int xa = max(x0, 0) >> 3, xb = min(x1, w - 1) >> 3, ya = max(y0, 0) >> 3, yb = min(y1, h - 1) >> 3;
+        bool hit = false;
+        for (int ty = ya; ty <= yb; ty++)
+            for (int tx = xa; tx <= xb; tx++)
+                if ((int)ld_l2(&c.tep[ty * tX + tx]) > snap) hit = true;
+        return hit;
     };
     // Commits a result that marks usedMap (accepted line: code 3 + epoch; rejected region: code 2), at the cursor, under
     // the cursor lock: pv = lane j < 12: field j of the rectangle (structRec order); m_src: the pixels to mark (null: this
@@ -1372,41 +1454,88 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         got = __builtin_amdgcn_readfirstlane(got);
         if (!got) return;
         while (true) {
-            const int f = lds_ld(&s_commit);
+            int f = lds_ld(&s_commit);
             if (f >= nseeds) break;
+            if (!trace) {
+                // a run of up to 64 records that need nothing but the cursor's nod (skipped seeds, results without marks that no
+                // line accepted since their snapshot can have touched), one record per lane
+                const int now = lds_ld(&s_epoch);
+                const int idx = f + lane;
+                const int rr = idx & (RW - 1);
+                const int stl = idx < nseeds ? st_ld(&rg.state[rr]) : R_EMPTY;
+                const uint32_t sp = idx < nseeds ? seedpos[idx] : 0u;           // (used only when a box has to be placed)
+                bool ok = stl == R_SKIP;
+                if (stl == R_LIGHT || stl == R_LIGHTL) {
+                    const int d = (now - (int)rg.snap[rr]) & 0xffff;
+                    ok = d == 0;
+                    if (!ok) {
+                        const uint32_t ax = rg.aux[rr];
+                        int x0, y0, x1, y1;
+                        if (stl == R_LIGHT) {
+                            const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
+                            x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
+                            x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
+                        } else { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
+                        // (the tile test only for the small boxes: a full evaluation's box may span the image, its lists say more)
+                        ok = !hit_since(now - d, now, x0, y0, x1, y1) || (stl == R_LIGHT && !box_tile_hit(now - d, x0, y0, x1, y1));
+                    }
+                }
+                const unsigned long long okm = ballot64(ok);
+                const int run = okm == ~0ull ? 64 : __builtin_ctzll(~okm);
+                if (run > 0) {
+                    const unsigned long long runm = run == 64 ? ~0ull : (1ull << run) - 1ull;
+                    const int nl = __builtin_popcountll(ballot64(stl != R_SKIP) & runm);
+                    if (lane < run) rg.state[rr] = (uint8_t)R_EMPTY;
+                    if (lane == 0) { s_ntrace = s_ntrace + nl; lds_st(&s_commit, f + run); }
+                    f += run;
+                    if (run == 64 || f >= nseeds) continue;
+                }
+            }
             const int r = f & (RW - 1);
-            const int st = lds_ld(&rg.state[r]);
+            const int st = st_ld(&rg.state[r]);
             if (st == R_SKIP) {
-                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
-            if (st == R_LIGHT) {
-                const int snap = rg.snap[r], now = lds_ld(&s_epoch);
-                const short* bx = rg.box[r];
-                if (now != snap && hit_since(snap, now, bx[0], bx[1], bx[2], bx[3])) {
-                    const uint32_t lr = rg.lref[r], lc = rg.lcnt[r];
-                    bool conflict = true;
-                    if (lr != ~0u) {                       // the lists are still in their slot: look at the pixels themselves
-                        wg_fence();
-                        conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap, (int)(lc & 0xffffu) + (int)(lc >> 16), snap);
-                    }
-                    if (conflict) {
-                        if (lane == 0) lds_st(&rg.state[r], R_REDO);
-                        break;
+            if (st == R_LIGHT || st == R_LIGHTL) {
+                const int now = lds_ld(&s_epoch);
+                const int d = (now - (int)rg.snap[r]) & 0xffff, snap = now - d;
+                const uint32_t ax = rg.aux[r];
+                if (d != 0) {
+                    int x0, y0, x1, y1;
+                    if (st == R_LIGHT) {
+                        const uint32_t sp = seedpos[f];
+                        const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
+                        x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
+                        x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
+                    } else { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
+                    if (hit_since(snap, now, x0, y0, x1, y1) && (st == R_LIGHTL || box_tile_hit(snap, x0, y0, x1, y1))) {
+                        bool conflict = true;
+                        if (st == R_LIGHTL && (stab.lcnt[ax] & 0xffffu) != 0u) {   // the lists are still in their slot: look at the pixels themselves
+                            const uint32_t lc = stab.lcnt[ax];
+                            wg_fence();
+                            conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + ax) * b.gcap, (int)(lc & 0xffffu) - 1 + (int)(lc >> 16), snap);
+                        }
+                        if (conflict) {
+                            STAT(ST_REDO, 1);
+                            if (lane == 0) { st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }
+                            DSTAT(ST_DEPTHDN, 1);
+                            break;
+                        }
                     }
                 }
                 bool used_now = false;
-                if (trace) used_now = (c.pw[ord[seedidx[f]]] & 3u) != 0u;     // the reference skips it then (:222): no record
+                if (trace) used_now = (c.pw[seedpos[f]] & 3u) != 0u;          // the reference skips it then (:222): no record
                 if (trace && !used_now) {
                     const int no = rnum[r * 2 + 1];
                     write_trace(f, rnum[r * 2], no >> 2, no & 3, 0.0);
                 } else if (!trace) write_trace(f, 0, 0, 0, 0.0);
-                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             if (st == R_STASH) {
                 // ---- a stashed result at the cursor: is it still what the sequential run would get? ----
-                const uint32_t lr = rg.lref[r];
+                const uint32_t lr = rg.aux[r];
                 wg_fence();
                 const double pv = b.pend[(img * (size_t)(NW * NS) + lr) * 24 + (lane < 24 ? lane : 0)];
                 const double logNFA = rl(pv, 12);
@@ -1417,9 +1546,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 const int st_n1 = (int)(pk3 % 32768ll) - 1, st_n2 = (int)((pk3 / 32768ll) % 32768ll);
                 const uint32_t* st_list = b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap;
                 const uint32_t* m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
-                if ((c.pw[ord[seedidx[f]]] & 3u) != 0u) {  // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
+                if ((c.pw[seedpos[f]] & 3u) != 0u) {       // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
                     STAT(ST_DISCARD, 1);
-                    if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                    if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }
                     continue;
                 }
                 const int now = lds_ld(&s_epoch);
@@ -1428,12 +1557,13 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (st_n1 >= 0) conflict = examined_hit(st_list, st_n1 + st_n2, snap);   // the pixels themselves
                     if (conflict) {
                         STAT(ST_REDO, 1);
-                        if (lane == 0) lds_st(&rg.state[r], R_REDO);     // evaluate again; everything earlier is committed now
+                        if (lane == 0) { st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }     // evaluate again; everything earlier is committed now
+                        DSTAT(ST_DEPTHDN, 1);
                         break;
                     }
                 }
                 commit_marks(f, num0, num, outcome, logNFA, pv, m_src, m_cnt);
-                if (lane == 0) { rg.state[r] = R_EMPTY; lds_st(&s_commit, f + 1); }
+                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
             break;
@@ -1446,62 +1576,313 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
     int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
-    int win_k0 = -64;                                      // window of seeds in registers (see the seed loop)
-    uint32_t win_pp = 0u;
-    unsigned long long win_used = 0ull;
     const unsigned long long ltm = (1ull << lane) - 1ull;
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
 #define LT(i) do { const long long t_ = NOW(); DSTAT((i), t_ - tl); tl = t_; } while (0)
     bool adv = false;                                      // a record has been published since the cursor was last looked at
+
+    // ---- The small-region grower: eight seeds side by side ----
+    // Nine seeds in ten grow a region of fewer than regThre (12..16) pixels and are dropped at once (:228), and such a region
+    // keeps 8 of the 64 lanes of grow() busy.  So the wave's eight 8-lane GROUPS each grow the region of one seed, one list
+    // entry x its 8 neighbours per step, out of a private 16x16-pixel window of packed pixel words around the seed (LDS,
+    // loaded once per seed: a small region cannot leave it without being given up first).  The candidates of an entry are
+    // decided in reference order against the estimated sum vector exactly as grow() decides a batch pixel by pixel; a test too
+    // close to call, a neighbour outside the window or a region that reaches regThre pixels hands the seed over to a full
+    // evaluation (R_BIG), which starts from scratch.  A region that reaches its fixpoint first is what RegionGrower returns
+    // for that seed, decision for decision; nothing of usedMap is written, so the result is published as R_LIGHT with the
+    // box of what it examined.  Groups take the next seed of the wave's chunk as they finish.
+    const int grp = lane >> 3, kq = lane & 7;
+    const int kk8 = kq + (kq >= 4);                         // 3x3 neighbourhood, row-major, centre skipped (:533-534)
+    const int ox = kk8 % 3 - 1, oy = kk8 / 3 - 1;
+    int ncap = 1;                                           // a group gives its seed up when the region reaches ncap pixels
+    if (g.regThre > 1.0 && g.degThre < 1.5) ncap = g.regThre >= (double)SCAP ? SCAP : (int)ceil(g.regThre);
+    const float cos_tol_s = (float)g_tol0[2];
+    uint32_t* const swin = &g_tw[wave][grp * 256];          // this group's window (the tile cache is not in use meanwhile)
+    uint32_t* const slst = &g_lst[wave][grp * SCAP];        // this group's list: ly << 4 | lx
+    int gk = -1;                                            // seed of this lane's group, -1: idle
+    int gn = 0, gi = 0, gex = 0, gwx = 0, gwy = 0, gsnap = 0;
+    float gC = 0.0f, gS = 0.0f;                             // estimated sum vector of the group's region
+    int ch_k0 = 0, ch_sx = 0, ch_sy = 0;                    // the wave's chunk: lane j < CH holds seed ch_k0 + j
+    unsigned long long ch_pend = 0ull;                      // seeds of the chunk not handed to a group yet
+    bool tw_small = false;                                  // g_tw / g_lst hold windows and small lists (not tiles / a region list)
+    constexpr float kEpsS = 1.0e-5f;                        // kEpsU + the fp32 running sums of up to SCAP unit vectors
+
+    int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done
+    bool pend_spec = false;
+    int nwait = 0;                                          // consecutive looks that found nothing to do (watchdog)
     while (true) {
-        // (one call site: the cursor code is inlined once, not once per kind of result)
-        if (adv) { advance(); adv = false; }
-        // ---- choose the next job ----
-        int k, slot = 0;
-        bool spec;
+        if (adv) {
+            // (the cursor is worth a look only when the record it stands on is finished)
+            const int f0 = lds_ld(&s_commit);
+            const int s0 = f0 < nseeds ? st_ld(&rg.state[f0 & (RW - 1)]) : R_EMPTY;
+            LT(ST_TSELECT);
+            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH) advance();
+            adv = false;
+            LT(ST_TCOMMIT);
+        }
         LT(ST_TSELECT);
-        const int f = lds_ld(&s_commit);
-        {
-            // a record waiting to be redone at the cursor has priority
-            int won = 0;
-            if (f < nseeds && lds_ld(&rg.state[f & (RW - 1)]) == R_REDO) {
-                if (lane == 0) won = atomicCAS(&rg.state[f & (RW - 1)], R_REDO, R_BUSY) == R_REDO ? 1 : 0;
-                won = __builtin_amdgcn_readfirstlane(won);
-            }
-            if (won) { k = f; spec = false; }
-            else {
-                // a free slot (the cursor has passed its seed) and a seed left to hand out?
+        const unsigned long long actm = ballot64(gk >= 0);
+        const int nidle = 8 - __builtin_popcountll(actm & 0x0101010101010101ull);
+        bool progress = false;
+        int f = 0;
+        if (nidle >= (actm ? kFeed : 1)) {
+            // ---- feed the idle groups.  Between chunks (the seeds of a chunk are nobody else's) a wave first looks for a full
+            //      evaluation to claim; it starts it when the groups still at work have finished ----
+            f = lds_ld(&s_commit);
+            if (!ch_pend && pend_k < 0) {
+                const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
+                if (stf == R_REDO || stf == R_BIG) {
+                    // the record at the cursor: evaluated where everything earlier is committed, no result slot needed
+                    int won = 0;
+                    if (lane == 0) {
+                        won = st_cas(rg.state, f & (RW - 1), stf, R_BUSY) ? 1 : 0;
+                        if (won && stf == R_BIG) atomicSub(&s_nbig, 1);
+                    }
+                    won = __builtin_amdgcn_readfirstlane(won);
+                    if (won) { pend_k = f; pend_spec = false; }
+                }
                 const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
-                bool took = false;
-                if (freem && lds_ld(&s_next) < nseeds && lds_ld(&s_next) - f < RW - 2 * NW) {
-                    int k0 = 0;
-                    if (lane == 0) k0 = atomicAdd(&s_next, 1);
-                    k0 = __builtin_amdgcn_readfirstlane(k0);
-                    if (k0 < nseeds) { k = k0; slot = __builtin_ctzll(freem); spec = true; took = true; }
+                if (pend_k < 0 && freem != 0ull && __builtin_popcountll(freem) > NS - b.tun_big && lds_ld(&s_nbig) > 0) {   // (tun_big: results a wave may have waiting for the cursor)
+                    // the oldest seed waiting for a full evaluation: four records per lane and step
+                    const int lim = min(min(lds_ld(&s_next), nseeds), f + lds_ld(&s_depth));
+                    int kb = -1;
+                    for (int base = f & ~3; base < lim && kb < 0; base += 256) {
+                        const int i0 = base + 4 * lane;
+                        uint32_t x = i0 < lim ? __hip_atomic_load(reinterpret_cast<uint32_t*>(rg.state) + ((i0 & (RW - 1)) >> 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                        int first = -1;
+                        #pragma unroll
+                        for (int t = 3; t >= 0; t--)
+                            if (((x >> (8 * t)) & 0xffu) == (uint32_t)R_BIG && i0 + t >= f && i0 + t < lim) first = i0 + t;
+                        const unsigned long long bm = ballot64(first >= 0);
+                        if (bm) kb = __builtin_amdgcn_readlane(first, __builtin_ctzll(bm));
+                    }
+                    int won = 0;
+                    if (lane == 0 && kb >= 0) {
+                        const int tgt = kb == lds_ld(&s_commit) ? R_BUSY : R_EVAL;
+                        won = st_cas(rg.state, kb & (RW - 1), R_BIG, tgt) ? (tgt == R_BUSY ? 2 : 1) : 0;
+                        if (won) atomicSub(&s_nbig, 1);
+                    }
+                    won = __builtin_amdgcn_readfirstlane(won);
+                    if (won) {
+                        pend_k = kb; pend_spec = won == 1; pend_slot = __builtin_ctzll(freem);
+                        if (pend_spec && lane == pend_slot) slot_k_l = kb;      // the slot is taken until the cursor has passed seed kb
+                        progress = true;
+                    }
                 }
-                if (!took) {
-                    if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
-                    // nothing moved: every slot waits for the cursor, or nothing is left to hand out.  Sleep long enough that the
-                    // polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
-                    if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
-                    adv = true;                            // (look at the cursor again before asking for a job)
-                    LT(ST_WAIT);
-                    continue;
+                if (pend_k < 0) {
+                    // reserve the next chunk of seeds
+                    const int old = lds_ld(&s_next);
+                    if (old < nseeds && old + CH - f <= lds_ld(&s_depth)) {
+                        int got = 0;
+                        if (lane == 0) got = atomicCAS(&s_next, old, old + CH) == old ? 1 : 0;
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        progress = true;                       // (lost the race: somebody moved, look again)
+                        if (got) {
+                            ch_k0 = old;
+                            const int kx = old + lane;
+                            const bool valid = lane < CH && kx < nseeds;
+                            uint32_t pp = 0u, code = 1u;
+                            if (valid) { pp = seedpos[kx]; code = c.pw[pp] & 3u; }
+                            ch_sx = (int)(pp % (uint32_t)w); ch_sy = (int)(pp / (uint32_t)w);
+                            const bool used = valid && code != 0u;      // monotone: once used, always used (:222)
+                            if (used) st_st(&rg.state[kx & (RW - 1)], R_SKIP);
+                            if (ncap <= 1) {
+                                // no region is small under these parameters: every seed goes to a full evaluation
+                                if (valid && !used) st_st(&rg.state[kx & (RW - 1)], R_BIG);
+                                const int nbg = __builtin_popcountll(ballot64(valid && !used));
+                                if (lane == 0 && nbg) atomicAdd(&s_nbig, nbg);
+                            } else ch_pend = ballot64(valid && !used);
+                            adv = true;
+                        }
+                    }
                 }
             }
+            // idle groups take the next seeds of the chunk
+            const unsigned long long idle0 = ~actm & 0x0101010101010101ull;     // bit 8g: group g is idle
+            if (ch_pend && idle0) {
+                unsigned long long idle = idle0;
+                const int snap = lds_ld(&s_epoch);         // before anything of usedMap is read for these seeds
+                wg_fence();
+                bool ld = false;
+                while (idle && ch_pend) {
+                    const int j = __builtin_ctzll(ch_pend);
+                    ch_pend &= ch_pend - 1ull;
+                    const int gg = __builtin_ctzll(idle) >> 3;
+                    idle &= idle - 1ull;
+                    const int sxj = __builtin_amdgcn_readlane(ch_sx, j), syj = __builtin_amdgcn_readlane(ch_sy, j);
+                    if (grp == gg) { gk = ch_k0 + j; gwx = sxj - 7; gwy = syj - 7; ld = true; }
+                }
+                tw_small = true;
+                // the window: 16 rows of 16 packed pixel words around the seed; lane kq loads quarter kq & 3 of rows (kq >> 2) + 2 j
+                const int q4 = (kq & 3) * 4, r0 = kq >> 2;
+                const int x0 = gwx + q4;
+                uint32_t seedraw = 0u;
+                #pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int row = r0 + 2 * j, y = gwy + row;
+                    uint32_t v0 = kPwStatic, v1 = kPwStatic, v2 = kPwStatic, v3 = kPwStatic;   // outside the image: banned
+                    if (ld && (unsigned)y < (unsigned)h) {
+                        const uint32_t* rowp = c.pw + (size_t)y * w;
+                        if (x0 >= 0 && x0 + 3 < w) {
+                            struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
+                            const Q4 qv = *reinterpret_cast<const Q4*>(rowp + x0);
+                            v0 = qv.a; v1 = qv.b; v2 = qv.c; v3 = qv.d;
+                        } else {
+                            if ((unsigned)(x0 + 0) < (unsigned)w) v0 = rowp[x0 + 0];
+                            if ((unsigned)(x0 + 1) < (unsigned)w) v1 = rowp[x0 + 1];
+                            if ((unsigned)(x0 + 2) < (unsigned)w) v2 = rowp[x0 + 2];
+                            if ((unsigned)(x0 + 3) < (unsigned)w) v3 = rowp[x0 + 3];
+                        }
+                    }
+                    if (j == 3) seedraw = v3;              // (row 7, column 7 of the window: lane kq == 5 holds the seed's own word)
+                    if (ld) {
+                        uint4 o;
+                        o.x = (v0 & ~3u) | (v0 & 1u); o.y = (v1 & ~3u) | (v1 & 1u); o.z = (v2 & ~3u) | (v2 & 1u); o.w = (v3 & ~3u) | (v3 & 1u);
+                        *reinterpret_cast<uint4*>(&swin[row * 16 + q4]) = o;
+                    }
+                }
+                // seeds used meanwhile (:222); the others start with their own pixel (:515-520)
+                const unsigned long long usedm = ballot64(ld && kq == 5 && (seedraw & 3u) != 0u);
+                const bool used = ((usedm >> (lane & 56)) & 0xffull) != 0ull;
+                const uint32_t sw = swin[7 * 16 + 7];
+                if (ld && !used) {
+                    float s0, c0;
+                    fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
+                    gC = c0; gS = s0; gn = 1; gi = 0; gex = 1; gsnap = snap;
+                    if (kq == 0) { swin[7 * 16 + 7] = sw | 2u; slst[0] = (7u << 4) | 7u; }
+                }
+                if (ld && used) {
+                    if (kq == 0) st_st(&rg.state[gk & (RW - 1)], R_SKIP);
+                    gk = -1;
+                }
+                if (usedm) adv = true;
+                progress = true;
+                DSTAT(ST_SLOW, 1);                          // (refill rounds)
+                LT(ST_TREFILL);
+            }
         }
-        // The seed's pixel comes out of a window of 64 consecutive seeds kept in registers (lane j: seed win_k0 + j): three
-        // dependent loads (seed index -> sorted list -> pixel word) per 64 seeds instead of per seed, and the seeds already used
-        // when the window was loaded -- two thirds of them on the bench maps, once used is always used (:222) -- cost no load at all.
-        if (k < win_k0 || k >= win_k0 + 64) {
-            win_k0 = k;
-            const bool wv = k + lane < nseeds;
-            win_pp = wv ? ord[seedidx[k + lane]] : 0u;
-            win_used = ballot64(wv && (c.pw[win_pp] & 3u) != 0u);
+        if (ballot64(gk >= 0)) {
+            // ---- one step: every active group tests the 8 neighbours of its next list entry ----
+            const bool act = gk >= 0;
+            const uint32_t e = slst[act ? gi : 0];
+            const int lx = (int)(e & 15u) + ox, ly = (int)(e >> 4) + oy;
+            const bool inwin = ((unsigned)lx < 16u) & ((unsigned)ly < 16u);
+            const int cell = ((ly & 15) << 4) | (lx & 15);
+            const uint32_t word = swin[cell];
+            // a neighbour outside the window: the region is not small enough for this grower
+            bool bail = ((ballot64(act & !inwin) >> (lane & 56)) & 0xffull) != 0ull;
+            bool todo = act & inwin & ((word & 3u) == 0u) & !bail;        // :536-537 (2 is growable, Q5)
+            float sf, cf;
+            fast_sincos(__uint_as_float(word & ~3u), sf, cf);
+            while (ballot64(todo)) {
+                // all candidates still to come, against the estimate as it stands: the ones that clearly fail before the first
+                // one that does not are decided for good (nothing is accepted in between); that one must clearly pass
+                const float Vg = __builtin_amdgcn_sqrtf(gC * gC + gS * gS) * 1.000001f;
+                const float nr = (float)gn * inv_ub(fmaxf(Vg, 1e-3f));
+                const float ec = kEpsS * (1.0f + 2.1f * nr) + 5e-6f;
+                const float d1 = cf * gC + sf * gS;
+                const unsigned long long nfm = ballot64(todo & !(d1 < (cos_tol_s - ec) * Vg));
+                const unsigned long long pm = ballot64(d1 > (cos_tol_s + ec) * Vg);
+                const uint32_t byte = (uint32_t)(nfm >> (lane & 56)) & 0xffu;
+                const bool has = byte != 0u;
+                const int l = has ? __builtin_ctz(byte) : 0;
+                const int src = (lane & 56) + l;
+                const bool acc = has & (((pm >> src) & 1ull) != 0ull);
+                const float cl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(cf)));
+                const float sl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(sf)));
+                if (acc & (kq == l)) {
+                    swin[cell] = word | 2u;                                   // :549
+                    slst[gn] = (uint32_t)((ly << 4) | lx);                   // :551-556
+                }
+                gC += acc ? cl : 0.0f; gS += acc ? sl : 0.0f;                // :545-546 (estimate)
+                gn += acc ? 1 : 0;
+                bail = bail | (has & !acc) | (acc & (gn >= ncap));            // too close to call / not a small region
+                todo = todo & acc & !bail & (kq > l);
+            }
+            const int ni = gi + 1;
+            const bool sweep_end = act & !bail & (ni >= gn);                  // :529 (the list is live)
+            const bool done = sweep_end & (gn == gex);                       // :525 a sweep that added nothing
+            gex = sweep_end ? gn : gex;
+            gi = sweep_end ? 0 : ni;
+            const bool fin = act & (done | bail);
+            const unsigned long long finm = ballot64(fin & (kq == 0));
+            if (finm) {
+                // box of everything examined: the list's pixels and their 8-neighbourhoods, relative to the seed (window cell 7, 7)
+                const uint32_t e0 = slst[kq < gn ? kq : 0], e1 = slst[kq + 8 < gn ? kq + 8 : 0];
+                const int bx0 = imin8(min((int)(e0 & 15u), (int)(e1 & 15u))), bx1 = imax8(max((int)(e0 & 15u), (int)(e1 & 15u)));
+                const int by0 = imin8(min((int)(e0 >> 4), (int)(e1 >> 4))), by1 = imax8(max((int)(e0 >> 4), (int)(e1 >> 4)));
+                const bool light = fin & !bail;
+                if (fin & (kq == 0)) {
+                    const int r = gk & (RW - 1);
+                    if (light) {
+                        rg.snap[r] = (uint16_t)gsnap;
+                        rg.aux[r] = (uint32_t)(bx0 - 8 + 32) | ((uint32_t)(by0 - 8 + 32) << 6) | ((uint32_t)(bx1 - 6 + 32) << 12) | ((uint32_t)(by1 - 6 + 32) << 18);
+                        if (trace) { rnum[r * 2] = gn; rnum[r * 2 + 1] = gn << 2; }
+                    }
+                    st_st(&rg.state[r], light ? R_LIGHT : R_BIG);
+                }
+                const unsigned long long lightm = ballot64(light & (kq == 0));
+                const int nbg = __builtin_popcountll(finm & ~lightm);
+                if (lane == 0 && nbg) atomicAdd(&s_nbig, nbg);
+                int gsum = 0;
+                for (unsigned long long t = lightm; t; t &= t - 1ull) gsum += __builtin_amdgcn_readlane(gn, __builtin_ctzll(t));
+                STAT(ST_GROW, __builtin_popcountll(lightm)); STAT(ST_GROWN, gsum); DSTAT(ST_SMALLBAIL, nbg);
+                gk = fin ? -1 : gk;
+                adv = true;
+            }
+            DSTAT(ST_SMALLSTEPS, 1);
+            LT(ST_TSMALL);
+            nwait = 0;
+            continue;
         }
-        const uint32_t pp = (uint32_t)__builtin_amdgcn_readlane((int)win_pp, k - win_k0);
-        const bool skip_known = ((win_used >> (k - win_k0)) & 1ull) != 0ull;
+        int k = -1, slot = 0;
+        bool spec = false;
+        if (pend_k >= 0) { k = pend_k; spec = pend_spec; slot = pend_slot; pend_k = -1; nwait = 0; }
+        else {
+            if (progress) { nwait = 0; continue; }
+            if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
+            // Watchdog: the protocol has no state in which every wave waits; should one arise all the same (a defect), the image
+            // is given up after seconds of nobody moving instead of hanging the device: counts[img] = -1, the state goes to stats.
+            if (lds_ld(&s_commit) != f) nwait = 0;
+            if (++nwait > LSD_REGION_WATCHDOG || lds_ld(&s_abort)) {
+                if (b.stats && lane == 0) {
+                    long long* st = b.stats + img * kStatWords;
+                    if (!lds_ld(&s_abort)) {
+                        const int fc = lds_ld(&s_commit);
+                        st[40] = fc; st[41] = lds_ld(&s_next); st[42] = nseeds; st[43] = fc < nseeds ? st_ld(&rg.state[fc & (RW - 1)]) : -1;
+                        st[44] = lds_ld(&s_nbig); st[45] = lds_ld(&s_lock); st[46] = pend_k; st[47] = wave;
+                    }
+                    st[24 + 2 * wave] = (long long)ch_k0 | ((long long)(pend_k + 1) << 32);     // what this wave holds (developer record)
+                    st[25 + 2 * wave] = (long long)ch_pend;
+                }
+                if (lane == 0) lds_st(&s_abort, 1);
+                break;
+            }
+            // within the look-ahead there is nothing for this wave (no seed to hand out, no evaluation to claim): look further
+            if (nwait == 1 && lane == 0 && lds_ld(&s_next) < nseeds) {
+                const int d = lds_ld(&s_depth);
+                if (d < depth_max) lds_st(&s_depth, min(d + kDepthUp, depth_max));
+            }
+            DSTAT(ST_DEPTHUP, nwait == 1 ? 1 : 0);
+            // nothing to do: every slot waits for the cursor, the ring is full, or nothing is left to hand out.  Sleep long
+            // enough that the polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
+            if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
+            adv = true;                                    // (look at the cursor again before asking for a job)
+#ifdef LSD_REGION_STATS
+            {   // why this wave had nothing to do: no result slot for a waiting seed / the ring is full / no seed is left
+                const int old = lds_ld(&s_next);
+                const long long t_ = NOW();
+                const int why = old >= nseeds ? ST_WNOSEED : (lds_ld(&s_nbig) > 0 ? ST_WNOSLOT : (old + CH - f > RW ? ST_WRING : ST_WAIT));
+                DSTAT(why, t_ - tl); tl = t_;
+            }
+#else
+            LT(ST_WAIT);
+#endif
+            continue;
+        }
+        // ---- a full evaluation of seed k (RegionGrower ... RectangleImprover with all 64 lanes) ----
+        const uint32_t pp = seedpos[k];
         const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
         int outcome = 0, num = 0, num0 = 0;
@@ -1509,14 +1890,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         double pv = 0;                                     // lane j < 12: field j of the result's rectangle (structRec order)
         int rec_pk = 0;
         // ---- evaluate ----
-        if (lane == slot && spec) slot_k_l = k;            // the slot is taken until the cursor has passed seed k
         const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
         wg_fence();
-        if (!spec || epoch_snap != g_ws[wave].cache_epoch) {   // tiles fetched before the last accept may miss its bans
+        if (tw_small || !spec || epoch_snap != g_ws[wave].cache_epoch) {   // tiles fetched before the last accept may miss its bans
             invalidate_tiles(c);
             g_ws[wave].cache_epoch = epoch_snap;
+            tw_small = false;
         }
-        const bool skip = skip_known || (c.pw[pp] & 3u) != 0u;   // monotone: once used, always used (:222)
+        const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
         int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
         // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
         uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
@@ -1575,13 +1956,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (!skip && outcome >= 2) commit_marks(k, num0, num, outcome, logNFA, pv, nullptr, 0);
             else if (!skip) write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             wg_fence();
-            if (lane == 0) { rg.state[k & (RW - 1)] = R_EMPTY; lds_st(&s_commit, k + 1); }
+            if (lane == 0) { rg.state[k & (RW - 1)] = (uint8_t)R_EMPTY; lds_st(&s_commit, k + 1); }
             LT(ST_TCOMMIT);
+            adv = true;
             continue;
         }
         if (skip) {
             if (lane == slot) slot_k_l = -1;               // nothing kept in the slot
-            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_SKIP);
+            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_SKIP);
             adv = true;
             continue;
         }
@@ -1603,15 +1985,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         if (n1 > 32767 || n2 > 32767) precise = false;     // (the sizes travel in 15-bit fields)
         if (outcome <= 1) {                                // nothing to mark: publish and move on
             if (lane == 0) {
-                const int r = k & (RW - 1);
-                rg.snap[r] = epoch_snap;
-                rg.box[r][0] = (short)x0; rg.box[r][1] = (short)y0; rg.box[r][2] = (short)x1; rg.box[r][3] = (short)y1;
-                rg.lref[r] = precise ? (uint32_t)(wave * NS + slot) : ~0u;
-                rg.lcnt[r] = precise ? ((uint32_t)n1 | ((uint32_t)n2 << 16)) : 0u;
+                const int r = k & (RW - 1), si = wave * NS + slot;
+                rg.snap[r] = (uint16_t)epoch_snap;
+                rg.aux[r] = (uint32_t)si;
+                stab.box[si][0] = (short)x0; stab.box[si][1] = (short)y0; stab.box[si][2] = (short)x1; stab.box[si][3] = (short)y1;
+                stab.lcnt[si] = precise ? ((uint32_t)(n1 + 1) | ((uint32_t)n2 << 16)) : 0u;
                 if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
             }
             wg_fence();                                    // the lists are in the slot before the record says so
-            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_LIGHT);
+            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_LIGHTL);
             adv = true;
             continue;
         }
@@ -1646,7 +2028,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
         }
         if (redo) {
-            if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_REDO);
+            if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_REDO);
             STAT(ST_REDO, 1);
             adv = true;
             continue;
@@ -1659,24 +2041,24 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             P[18] = (double)x0; P[19] = (double)y0; P[20] = (double)x1; P[21] = (double)y1;
             P[22] = (double)((long long)(precise ? n1 + 1 : 0) + 32768ll * n2 + 32768ll * 32768ll * m_off);
             P[23] = (double)epoch_snap;
-            rg.lref[k & (RW - 1)] = (uint32_t)(wave * NS + slot);
+            rg.aux[k & (RW - 1)] = (uint32_t)(wave * NS + slot);
         }
         wg_fence();                                        // record and lists are in the slot before the ring says so
-        if (lane == 0) lds_st(&rg.state[k & (RW - 1)], R_STASH);
+        if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_STASH);
         adv = true;
     }
 
     __syncthreads();
     if (threadIdx.x == 0) {
-        b.counts[img] = s_lines;
+        b.counts[img] = s_abort ? -1 : s_lines;
         if (b.nseed) b.nseed[img] = s_ntrace;
     }
     if (b.stats) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * 32);
-        if (lane == 0 && wave == 0) { g_stat[c.wave][ST_TOTAL] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][ST_SEEDS] = (unsigned long long)nseeds; }
-        if (lane < ST_COUNT) {
-            if (lane == ST_MAXREG || lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][lane]);
-            else atomicAdd(&st[lane], g_stat[c.wave][lane]);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
+        if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth)); }
+        if (lane < ST_COUNT && !s_abort && (sslot(lane) != 11 || kStatSlots == ST_COUNT)) {
+            if (lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][sslot(lane)]);
+            else atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
         }
     }
 }

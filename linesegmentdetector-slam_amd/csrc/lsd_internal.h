@@ -9,6 +9,7 @@ namespace lsdhip {
 constexpr double kPi = 3.14159265358979323846;  // == 4.0*atan(1.0), myLSD.cpp:9
 constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per phase kernel
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries
+constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
 
 // Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
@@ -47,6 +48,7 @@ struct Buffers {
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
     uint32_t* pw;          // n x npx : packed pixel word (see above)
     uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3 (never initialised, read only behind code 3)
+    uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
@@ -59,9 +61,11 @@ struct Buffers {
     int* rnum;             // n x RW x 2 : sizes/outcome of published records (seed trace only)
     uint32_t* order;       // n : image indices, heaviest (largest nb) first: the region stage's workgroup -> image map
     uint32_t* seedidx;     // n x npx : sorted-list indices of the potential seeds (usedMap == 0 after the gradient pass)
+    uint32_t* seedpos;     // n x npx : their pixels (y*w+x), same order
     uint32_t* slist;       // n x NW x NS x gcap : lists of the speculative results in flight (examined pixels, pixels to mark)
     int gcap;
     uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())
+    int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)
@@ -76,7 +80,7 @@ struct Buffers {
     // debug
     void* seeds;           // n x npx trace records or null
     int32_t* nseed;        // n
-    long long* stats;      // n x 8
+    long long* stats;      // n x kStatWords
 };
 
 struct SeedRec {  // mirrors oracle's orc_seed

@@ -23,8 +23,9 @@ for rep in range(reps):
     bad = np.nonzero(c < 0)[0]
     print("rep", rep, "%.1f ms" % (dt * 1e3), "region %.1f" % ctx.timings()["region"], "lines", int(c[c > 0].sum()), "aborted", bad.tolist(), flush=True)
     for i in bad[:4]:
-        st = ctx.fetch(int(i), lsd.DBG_STATS, wh)
-        v = list(st.values())
+        v = np.zeros(48, np.int64)                           # the raw stats record: the watchdog's words are 40..47, per-wave words 24..39
+        assert ctx.L.lsd_debug_fetch(ctx.h, int(i), lsd.DBG_STATS, v.ctypes.data, v.nbytes) == 0
+        v = [int(x) for x in v]
         print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[40:48])), flush=True)
         print("      per wave (chunk start, pend_k, ch_pend):", [(x & 0xffffffff, (x >> 32) - 1, hex(y)) for x, y in zip(v[24:40:2], v[25:40:2])], flush=True)
     cur = (c.tobytes(), lines.cpu().numpy().tobytes())

@@ -27,5 +27,5 @@ for si, name in enumerate(bench.SOURCES):
     idx = [i for i in range(n) if i % 4 == si]
     f = lambda key: np.mean([st[i][key] for i in idx]) / 1e6
     print("  %-10s %3d  %5.0f %5.0f   wait %5.0f eval %5.0f (grow %5.0f sums %4.0f rect %4.0f nfa %4.0f refine %4.0f) idle %5.0f commit %4.0f  seeds %6.0f grows %6.0f lines %s" % (
-        name, len(idx), tot[idx].mean(), tot[idx].max(), f("cycles_wait"), f("cycles_eval"), f("cycles_grow"), f("cycles_sums"), f("cycles_rect"), f("cycles_nfa"), f("cycles_refine"), 0.0, f("cycles_commit"),
+        name, len(idx), tot[idx].mean(), tot[idx].max(), f("cycles_wait"), f("cycles_eval"), f("cycles_grow"), f("cycles_sums"), f("cycles_rect"), f("cycles_nfa"), f("cycles_refine"), f("cycles_small"), f("cycles_commit"),
         np.mean([st[i]["seeds"] for i in idx]), np.mean([st[i]["grow_calls"] for i in idx]), ""))
