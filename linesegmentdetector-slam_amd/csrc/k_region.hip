@@ -1371,12 +1371,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             s_ntrace = s_ntrace + 1;
         }
     };
-    // True if a pixel examined by a region (a member or one of its 8 neighbours) was banned by a line accepted in epoch
-    // >= snap: only then can the region's evaluation differ from what it would be now (it read usedMap only as
-    // "banned?", and only accepted lines ban).  Accepted pixels carry their line's epoch + 1 in epochmap.
+    // True if a MEMBER of a region's grown lists was banned by a line accepted in epoch >= snap: only then can the region's
+    // evaluation differ from what it would be now.  (It read usedMap only as "banned?" of candidate pixels, :537.  A pixel it
+    // examined and did NOT take -- the angle test failed every time it came up -- is skipped now instead of failing: the same
+    // sequence of accepts, the same sums, the same lists.  A pixel it took would now be skipped: a different region.  So the
+    // neighbours of the lists do not matter, the lists do.)  Accepted pixels carry their line's epoch + 1 in epochmap.
     auto examined_hit = [&](const uint32_t* lp, int cnt, int snap) -> bool {
         // first by tiles (tep[] is a few KB and stays in the cache): no line accepted since the snapshot has a pixel in any tile
-        // the region's pixels or their neighbours lie in -> nothing examined can have been banned
+        // a member lies in
         const int tX = c.tilesX;
         bool thit = false;
         for (int base = 0; base < cnt; base += 64) {
@@ -1384,8 +1386,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (k2 < cnt) {
                 const uint32_t pkx = lp[k2];
                 const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
-                const int xa = max(x - 1, 0) >> 3, xb = min(x + 1, w - 1) >> 3, ya = max(y - 1, 0) >> 3, yb = min(y + 1, h - 1) >> 3;
-                if ((int)ld_l2(&c.tep[ya * tX + xa]) > snap || (int)ld_l2(&c.tep[ya * tX + xb]) > snap || (int)ld_l2(&c.tep[yb * tX + xa]) > snap || (int)ld_l2(&c.tep[yb * tX + xb]) > snap) thit = true;
+                if ((int)ld_l2(&c.tep[(y >> 3) * tX + (x >> 3)]) > snap) thit = true;
             }
         }
         if (!ballot64(thit)) return false;
@@ -1394,15 +1395,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             const int k2 = base + lane;
             if (k2 < cnt) {
                 const uint32_t pkx = lp[k2];
-                const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
-                #pragma unroll
-                for (int t9 = 0; t9 < 9; t9++) {
-                    const int xx = x + t9 % 3 - 1, yy = y + t9 / 3 - 1;
-                    if (xx >= 0 && yy >= 0 && xx < w && yy < h) {
-                        const size_t q = (size_t)yy * w + xx;
-                        if ((c.pw[q] & 3u) == kPwLine && (int)c.epochmap[q] > snap) hit = true;
-                    }
-                }
+                const size_t q = (size_t)(pkx >> 16) * w + (pkx & 0xffffu);
+                if ((c.pw[q] & 3u) == kPwLine && (int)c.epochmap[q] > snap) hit = true;
             }
         }
         return ballot64(hit) != 0ull;
@@ -1808,7 +1802,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             const bool fin = act & (done | bail);
             const unsigned long long finm = ballot64(fin & (kq == 0));
             if (finm) {
-                // box of everything examined: the list's pixels and their 8-neighbourhoods, relative to the seed (window cell 7, 7)
+                // box of the list's pixels, relative to the seed (window cell 7, 7): what a line accepted before the seed's turn must not touch
                 const uint32_t e0 = slst[kq < gn ? kq : 0], e1 = slst[kq + 8 < gn ? kq + 8 : 0];
                 const int bx0 = imin8(min((int)(e0 & 15u), (int)(e1 & 15u))), bx1 = imax8(max((int)(e0 & 15u), (int)(e1 & 15u)));
                 const int by0 = imin8(min((int)(e0 >> 4), (int)(e1 >> 4))), by1 = imax8(max((int)(e0 >> 4), (int)(e1 >> 4)));
@@ -1817,7 +1811,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     const int r = gk & (RW - 1);
                     if (light) {
                         rg.snap[r] = (uint16_t)gsnap;
-                        rg.aux[r] = (uint32_t)(bx0 - 8 + 32) | ((uint32_t)(by0 - 8 + 32) << 6) | ((uint32_t)(bx1 - 6 + 32) << 12) | ((uint32_t)(by1 - 6 + 32) << 18);
+                        rg.aux[r] = (uint32_t)(bx0 - 7 + 32) | ((uint32_t)(by0 - 7 + 32) << 6) | ((uint32_t)(bx1 - 7 + 32) << 12) | ((uint32_t)(by1 - 7 + 32) << 18);
                         if (trace) { rnum[r * 2] = gn; rnum[r * 2 + 1] = gn << 2; }
                     }
                     st_st(&rg.state[r], light ? R_LIGHT : R_BIG);
@@ -1967,12 +1961,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             adv = true;
             continue;
         }
-        // box of everything this evaluation examined (region pixels and their 8-neighbourhoods)
+        // box of the pixels of this evaluation's grown lists
         int x0, y0, x1, y1;
         {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
             Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
             fb = list_bbox(c.wave, gnum, fb, has_copy);
-            x0 = fb.x0 - 1; y0 = fb.y0 - 1; x1 = fb.x1 + 1; y1 = fb.y1 + 1;
+            x0 = fb.x0; y0 = fb.y0; x1 = fb.x1; y1 = fb.y1;
         }
         bool precise = n1 >= 0;
         int n2 = 0;
