@@ -104,6 +104,8 @@ struct RCtx {
     double logNT;
     const double* lgamma;
     const double* ptab;
+    uint32_t* wslist;    // this wave's result slots: [NS][gcap] list entries
+    int gcap;
 };
 
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
@@ -151,6 +153,16 @@ __shared__ RCtx g_ctx[NW];                                // the wave's context:
                                                           // (a struct passed by value travels through scratch memory at every call)
 __shared__ double g_tol0[3];                              // the global tolerance (degThre) with its sine and cosine: every first grow uses it
 __shared__ double g_acc[NW][32 * 4];                      // staging of the serial (bit-exact) sums: 32 list elements x up to 4 terms
+// what eval_seed() leaves for its caller (the rectangle itself stays in g_ws[wave].rec)
+struct EvalOut {
+    int skip, outcome, num, num0, rec_pk;
+    int x0, y0, x1, y1;      // box of the pixels of the grown lists (speculative evaluations only)
+    int n1, n2, precise;     // sizes of the first grow and of Refiner's regrow kept in the slot (precise == 0: not kept)
+    int m_off, mcnt, redo;   // where the pixels to mark sit in the slot; redo: the result does not fit a slot
+    double logNFA;
+};
+__shared__ EvalOut g_eo[NW];
+__shared__ double g_par[4];                               // degThre, regThre, aliPro, denThre of the launch (Geom)
 
 // The reference's sums over a region (moments, angle sums, Refiner's statistics) are plain left-to-right fp64 additions, and
 // their rounding decides accept/reject ties, so they are added in exactly that order: the lanes compute the terms of 32 list
@@ -1224,6 +1236,128 @@ __device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) 
     return bx;
 }
 
+// One seed's evaluation, RegionGrower ... RectangleImprover (:225-240), with all 64 lanes of the wave; pp = the seed's pixel.
+// A speculative evaluation (spec != 0) also leaves in result slot `slot` what the commit at the cursor will need: the first
+// grow's list and Refiner's regrow (their pixels decide whether the result is still valid at its turn), and the pixels to mark.
+// The outcome goes to g_eo[wave] (all lanes store the same values), the rectangle stays in g_ws[wave].rec.
+__device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slot_) {
+    RCtx c = g_ctx[uni(cw_)];
+    c.lane = (int)(threadIdx.x & 63);
+    const int lane = c.lane, wave = c.wave, w = c.w;
+    const uint32_t pp = (uint32_t)uni((int)pp_);
+    const bool spec = uni(spec_) != 0;
+    const int slot = uni(slot_);
+    const int gcap = c.gcap;
+    const double p_degThre = g_par[0], p_regThre = g_par[1], p_aliPro = g_par[2], p_denThre = g_par[3];
+    const unsigned long long ltm = (1ull << lane) - 1ull;
+    const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
+    EvalOut& eo = g_eo[wave];
+
+    int outcome = 0, num = 0, num0 = 0, rec_pk = 0;
+    double logNFA = 0;
+    const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
+    int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
+    // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
+    uint32_t* const gl0 = c.wslist + (size_t)slot * gcap;
+    int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
+    bool regrown = false;
+    if (!skip) {
+        // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
+        // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
+        // re-estimated by Refiner (:833-857).
+        const double seedDeg = c.deg[pp];
+        double tol = p_degThre, regdeg = seedDeg;
+        bool done = false;
+        for (int pass = 0; pass < 2 && !done; pass++) {
+            num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
+            if (pass == 0 && spec && num <= gcap) {                // keep the first list for the validation at the cursor
+                for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
+                n1 = num;
+            }
+            if (pass == 1) regrown = true;
+            if (pass == 0) {
+                num0 = num;
+                if (num < p_regThre) { done = true; break; }                      // :228 (not marked, Q5)
+            } else if (num < 2) { outcome = 1; done = true; break; }              // :861
+            if (num > 1) { exact_sums(c.wave, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
+            else regdeg = seedDeg;
+            rect_convert(c.wave, num, regdeg, p_aliPro, 0, p_degThre);                 // :232 / :866 (p, prec still the defaults)
+            const double den = rec_density(num, g_ws[wave].rec);
+            if (pass == 0) {
+                if (den >= p_denThre) break;                                      // :829 dense enough
+                if (spec) {                                                       // the regrow replaces this list
+                    Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
+                    fb = list_bbox(c.wave, num, fb, false);
+                    fx0 = fb.x0; fy0 = fb.y0; fx1 = fb.x1; fy1 = fb.y1;
+                }
+                tol = refine_tol(c.wave, sx, sy, num, seedDeg);                        // :833-855
+            } else if (den < p_denThre) {                                         // :869-877
+                const int r = radius_reduce(c.wave, sx, sy, num, regdeg, p_denThre);   // (lst reordered: gcopy holds the grow-order list)
+                if (r < 0) { num = -r - 1; outcome = 1; done = true; }
+                else num = r;
+            }
+        }
+        if (!done) {
+            logNFA = improve(c.wave);                                                  // :240
+            outcome = logNFA <= 0 ? 2 : 3;                                        // :242
+            rec_pk = g_ws[wave].rec.pk;
+        }
+    }
+    eo.skip = skip ? 1 : 0; eo.outcome = outcome; eo.num = num; eo.num0 = num0; eo.rec_pk = rec_pk; eo.logNFA = logNFA;
+    eo.redo = 0; eo.precise = 0; eo.n1 = 0; eo.n2 = 0; eo.m_off = 0; eo.mcnt = num;
+    if (!spec || skip) return;
+
+    const int gnum = g_ws[wave].gnum;                  // size of the last grow (grow order)
+    const bool has_copy = g_ws[wave].has_copy != 0;
+    // box of the pixels of this evaluation's grown lists
+    {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
+        Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
+        fb = list_bbox(c.wave, gnum, fb, has_copy);
+        eo.x0 = fb.x0; eo.y0 = fb.y0; eo.x1 = fb.x1; eo.y1 = fb.y1;
+    }
+    bool precise = n1 >= 0;
+    int n2 = 0;
+    if (regrown) {                                     // keep Refiner's regrow (in grow order, before any reduction) behind the first list
+        if (precise && n1 + gnum <= gcap) {
+            for (int k2 = lane; k2 < gnum; k2 += 64) gl0[n1 + k2] = has_copy ? c.gcopy[k2] : lget(c, k2);
+            n2 = gnum;
+        } else precise = false;
+    }
+    if (n1 > 32767 || n2 > 32767) precise = false;     // (the sizes travel in 15-bit fields)
+    eo.precise = precise ? 1 : 0; eo.n1 = n1; eo.n2 = n2;
+    if (outcome <= 1) return;                          // nothing to mark
+    // the pixels to mark
+    int m_off = 0, mcnt = num;                         // not regrown: the first list is exactly the region
+    bool redo = false;
+    if (!regrown) {
+        if (!precise) redo = true;                     // (larger than a list slot) evaluate again at the cursor
+    } else if (precise && !has_copy) { m_off = n1; mcnt = n2; }            // the regrow as it is
+    else {
+        m_off = precise ? n1 + n2 : 0;
+        if (m_off + gnum > gcap) { precise = false; m_off = 0; }
+        if (gnum > gcap) redo = true;
+        else {
+            wg_fence();                                // the stamps written by grow() must have landed
+            g_ws[wave].dirty = 0;
+            const uint32_t cur_id = g_ws[wave].cur_id;
+            mcnt = 0;
+            for (int base = 0; base < gnum; base += 64) {
+                const int k2 = base + lane;
+                uint32_t pkx = 0;
+                bool keep = false;
+                if (k2 < gnum) {
+                    pkx = has_copy ? c.gcopy[k2] : lget(c, k2);
+                    keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == cur_id;   // curMap == 1 only
+                }
+                const unsigned long long km = ballot64(keep);
+                if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
+                mcnt += __builtin_popcountll(km);
+            }
+        }
+    }
+    eo.precise = precise ? 1 : 0; eo.m_off = m_off; eo.mcnt = mcnt; eo.redo = redo ? 1 : 0;
+}
+
 __device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -1302,6 +1436,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
     }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
+    c.wslist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap; c.gcap = b.gcap;
+    if (threadIdx.x == 0) { g_par[0] = g.degThre; g_par[1] = g.regThre; g_par[2] = g.aliPro; g_par[3] = g.denThre; }
     if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
     if (lane < kStatSlots) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
@@ -1567,10 +1703,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 
     // Result slots of this wave: slot s holds the lists (and, for a result that marks usedMap, the record in pend[]) of
     // the speculative result of seed slot_k (lane s of slot_k_l); it is free again once the cursor has passed that seed.
-    uint32_t* const wave_slist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap;        // [NS][gcap]
     double* const wave_pend = b.pend + (img * NW + wave) * (size_t)NS * 24;
     int slot_k_l = -1;                                     // lane s < NS: seed whose result sits in slot s
-    const unsigned long long ltm = (1ull << lane) - 1ull;
     [[maybe_unused]] long long tl = NOW();
     // coarse accounting of this wave's time (s_memtime ticks since the last stamp go to slot i)
 #define LT(i) do { const long long t_ = NOW(); DSTAT((i), t_ - tl); tl = t_; } while (0)
@@ -1877,12 +2011,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         }
         // ---- a full evaluation of seed k (RegionGrower ... RectangleImprover with all 64 lanes) ----
         const uint32_t pp = seedpos[k];
-        const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
 
-        int outcome = 0, num = 0, num0 = 0;
-        double logNFA = 0;
-        double pv = 0;                                     // lane j < 12: field j of the result's rectangle (structRec order)
-        int rec_pk = 0;
         // ---- evaluate ----
         const int epoch_snap = lds_ld(&s_epoch);           // before anything of usedMap is read for this seed
         wg_fence();
@@ -1891,57 +2020,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             g_ws[wave].cache_epoch = epoch_snap;
             tw_small = false;
         }
-        const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
-        int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
-        // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
-        uint32_t* const gl0 = wave_slist + (size_t)slot * b.gcap;
-        int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
-        bool regrown = false;
-        if (!skip) {
-            // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
-            // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
-            // re-estimated by Refiner (:833-857).
-            const double seedDeg = c.deg[pp];
-            double tol = g.degThre, regdeg = seedDeg;
-            bool done = false;
-            for (int pass = 0; pass < 2 && !done; pass++) {
-                num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
-                if (pass == 0 && spec && num <= b.gcap) {              // keep the first list for the validation at the cursor
-                    for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
-                    n1 = num;
-                }
-                if (pass == 1) regrown = true;
-                if (pass == 0) {
-                    num0 = num;
-                    if (num < g.regThre) { done = true; break; }                      // :228 (not marked, Q5)
-                } else if (num < 2) { outcome = 1; done = true; break; }              // :861
-                if (num > 1) { exact_sums(c.wave, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
-                else regdeg = seedDeg;
-                rect_convert(c.wave, num, regdeg, g.aliPro, 0, g.degThre);                 // :232 / :866 (p, prec still the defaults)
-                const double den = rec_density(num, g_ws[wave].rec);
-                if (pass == 0) {
-                    if (den >= g.denThre) break;                                      // :829 dense enough
-                    if (spec) {                                                       // the regrow replaces this list
-                        Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-                        fb = list_bbox(c.wave, num, fb, false);
-                        fx0 = fb.x0; fy0 = fb.y0; fx1 = fb.x1; fy1 = fb.y1;
-                    }
-                    tol = refine_tol(c.wave, sx, sy, num, seedDeg);                        // :833-855
-                } else if (den < g.denThre) {                                         // :869-877
-                    const int r = radius_reduce(c.wave, sx, sy, num, regdeg, g.denThre);   // (lst reordered: gcopy holds the grow-order list)
-                    if (r < 0) { num = -r - 1; outcome = 1; done = true; }
-                    else num = r;
-                }
-            }
-            if (!done) {
-                logNFA = improve(c.wave);                                                  // :240
-                outcome = logNFA <= 0 ? 2 : 3;                                        // :242
-                pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;
-                rec_pk = g_ws[wave].rec.pk;
-            }
-        }
-        const int gnum = g_ws[wave].gnum;                  // size of the last grow (grow order)
-        const bool has_copy = g_ws[wave].has_copy != 0;
+        eval_seed(c.wave, pp, spec ? 1 : 0, slot);
+        const EvalOut& eo = g_eo[wave];
+        const bool skip = eo.skip != 0;
+        const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;
+        const double logNFA = eo.logNFA;
+        const double pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;   // lane j < 12: field j of the result's rectangle (structRec order)
 
         // ---- hand the result over ----
         LT(ST_TEVAL);
@@ -1961,22 +2045,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             adv = true;
             continue;
         }
-        // box of the pixels of this evaluation's grown lists
-        int x0, y0, x1, y1;
-        {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
-            Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-            fb = list_bbox(c.wave, gnum, fb, has_copy);
-            x0 = fb.x0; y0 = fb.y0; x1 = fb.x1; y1 = fb.y1;
-        }
-        bool precise = n1 >= 0;
-        int n2 = 0;
-        if (regrown) {                                     // keep Refiner's regrow (in grow order, before any reduction) behind the first list
-            if (precise && n1 + gnum <= b.gcap) {
-                for (int k2 = lane; k2 < gnum; k2 += 64) gl0[n1 + k2] = has_copy ? c.gcopy[k2] : lget(c, k2);
-                n2 = gnum;
-            } else precise = false;
-        }
-        if (n1 > 32767 || n2 > 32767) precise = false;     // (the sizes travel in 15-bit fields)
+        const int x0 = eo.x0, y0 = eo.y0, x1 = eo.x1, y1 = eo.y1, n1 = eo.n1, n2 = eo.n2, m_off = eo.m_off, mcnt = eo.mcnt;
+        const bool precise = eo.precise != 0, redo = eo.redo != 0;
         if (outcome <= 1) {                                // nothing to mark: publish and move on
             if (lane == 0) {
                 const int r = k & (RW - 1), si = wave * NS + slot;
@@ -1991,36 +2061,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             adv = true;
             continue;
         }
-        // marks to make: stash the result (record in pend[], the pixels to mark in the list slot); whoever moves the
+        // marks to make: the result is stashed (record in pend[], the pixels to mark in the list slot); whoever moves the
         // cursor over it commits it
-        int m_off = 0, mcnt = num;                         // not regrown: the first list is exactly the region
-        bool redo = false;
-        if (!regrown) {
-            if (!precise) redo = true;                     // (larger than a list slot) evaluate again at the cursor
-        } else if (precise && !has_copy) { m_off = n1; mcnt = n2; }            // the regrow as it is
-        else {
-            m_off = precise ? n1 + n2 : 0;
-            if (m_off + gnum > b.gcap) { precise = false; m_off = 0; }
-            if (gnum > b.gcap) redo = true;
-            else {
-                wg_fence();                                // the stamps written by grow() must have landed
-                g_ws[wave].dirty = 0;
-                const uint32_t cur_id = g_ws[wave].cur_id;
-                mcnt = 0;
-                for (int base = 0; base < gnum; base += 64) {
-                    const int k2 = base + lane;
-                    uint32_t pkx = 0;
-                    bool keep = false;
-                    if (k2 < gnum) {
-                        pkx = has_copy ? c.gcopy[k2] : lget(c, k2);
-                        keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == cur_id;   // curMap == 1 only
-                    }
-                    const unsigned long long km = ballot64(keep);
-                    if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
-                    mcnt += __builtin_popcountll(km);
-                }
-            }
-        }
         if (redo) {
             if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_REDO);
             STAT(ST_REDO, 1);
