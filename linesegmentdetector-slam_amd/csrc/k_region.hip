@@ -111,7 +111,7 @@ struct RCtx {
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
        ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_X5, ST_X6, ST_X7, ST_COUNT };
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_COUNT };
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
@@ -121,10 +121,10 @@ constexpr int kStatSlots = ST_COUNT;
 __device__ constexpr int sslot(int i) { return i; }
 #else
 // the product build keeps the always-on counters only (LDS is the scarce resource of this kernel)
-constexpr int kStatSlots = 14;
+constexpr int kStatSlots = 16;
 __device__ constexpr int sslot(int i) {
     return i == ST_GROW ? 0 : i == ST_GROWN ? 1 : i == ST_NFA ? 2 : i == ST_RRR ? 3 : i == ST_RRRPASS ? 4 : i == ST_SENT ? 5 : i == ST_OOB ? 6 :
-           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : 11;
+           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : i == ST_XEXP ? 14 : i == ST_XHELP ? 15 : 11;
 }
 #endif
 #define STAT(i, v) do { g_stat[c.wave][sslot(i)] += (unsigned long long)(v); } while (0)
@@ -190,6 +190,10 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
 // stale line in the L1 behind; plain stores of the same CU do not)
 __device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+// words shared with OTHER workgroups (the help protocol of the seed loop): written and read in L2, ordered by agent-scope fences
+__device__ __forceinline__ void st_l2(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void agent_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 // Function arguments arrive in vector registers even when they are the same in every lane; the inner loop wants them on
 // the scalar unit (scalar compares and branches, SGPR-base addressing of global memory with 32-bit lane offsets).
@@ -1375,7 +1379,12 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 //            whoever moves the cursor over it validates and commits it
 //   R_REDO   a speculative result was invalidated (or abandoned): must be evaluated again at the cursor
 //   R_BUSY   being evaluated at the cursor
-enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8 };
+//   R_REMOTE given to the wavefronts of other workgroups that help with this image (aux = request number); R_XLIGHTL / R_XSTASH:
+//            their answers, R_LIGHTL / R_STASH with the lists and the record in the HELPER's result slot (aux = request number,
+//            the slot and the box in the request table)
+enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8,
+       R_REMOTE = 9, R_XLIGHTL = 10, R_XSTASH = 11 };
+constexpr int kHelpIdle = 50;             // looks without a request after which a helper wavefront leaves an image
 constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
 constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
 constexpr int kDepthUp = 32, kDepthDown = 96;   // steps of the adaptive look-ahead (see the seed loop)
@@ -1415,8 +1424,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
     __shared__ SlotTab stab;
+    // seeds given to helpers: request j holds seed s_xk[j] (-1: free, -2: answered -- the answer, in the image's record of the
+    // help protocol in HBM, waits for the cursor)
+    __shared__ int s_nhelp, s_xout, s_xlock, s_xreg, s_xpub, s_idlecnt, s_xc_last, s_xt_last, s_workbound;
+    __shared__ int s_xk[kXReq];
 
     const size_t img = b.order[blockIdx.x];               // heaviest images first (k_order)
+    uint32_t* const xr = b.xq ? b.xq + img * (size_t)kXStride : nullptr;                    // this image's record of the help protocol
+    uint32_t* const xhdr = b.xq ? b.xq + (size_t)gridDim.x * kXStride : nullptr;             // ... and the launch's
+    if (threadIdx.x == 0 && xhdr) atomicAdd(&xhdr[0], 1u);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = g.w, h = g.h;
     const size_t npx = (size_t)g.npx;
@@ -1441,8 +1457,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
     if (lane < kStatSlots) g_stat[c.wave][lane] = 0ull;
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+    [[maybe_unused]] const long long rt_begin = (long long)__builtin_amdgcn_s_memrealtime();   // (100 MHz, the same on every CU)
     if (lane < NT) g_ttag[c.wave][lane] = -1;
     for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
+    if (threadIdx.x < kXReq) s_xk[threadIdx.x] = -1;
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
@@ -1470,7 +1488,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = cnt; s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = b.tun_stop > 0 ? min(cnt, b.tun_stop) : cnt; s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
         wg_fence();
     }
     __syncthreads();
@@ -1562,12 +1580,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
             const Box mb = mark_region(c.wave, (uint32_t)(lds_ld(&s_epoch) + 1), m_src, m_cnt);   // :259-265 (+ the line's epoch)
             wg_fence();                                   // the marks must be visible before the epoch moves
+            if (xr) agent_release();                      // ... to the helpers on other CUs as well
             if (lane == 0) {
                 const int ep = s_epoch;
                 short* r = s_ring[ep & (RING - 1)];
                 r[0] = (short)mb.x0; r[1] = (short)mb.y0; r[2] = (short)mb.x1; r[3] = (short)mb.y1;
                 s_lines = li + 1;
                 lds_st(&s_epoch, ep + 1);
+                if (xr) st_l2(&xr[0], (uint32_t)(ep + 1));
             }
             invalidate_tiles(c);                          // this wave's cached ban flags are stale now
             g_ws[wave].cache_epoch = -1;
@@ -1627,7 +1647,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
-            if (st == R_LIGHT || st == R_LIGHTL) {
+            if (st == R_LIGHT || st == R_LIGHTL || st == R_XLIGHTL) {
                 const int now = lds_ld(&s_epoch);
                 const int d = (now - (int)rg.snap[r]) & 0xffff, snap = now - d;
                 const uint32_t ax = rg.aux[r];
@@ -1638,22 +1658,31 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
                         x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
                         x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
-                    } else { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
-                    if (hit_since(snap, now, x0, y0, x1, y1) && (st == R_LIGHTL || box_tile_hit(snap, x0, y0, x1, y1))) {
+                    } else if (st == R_LIGHTL) { x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3]; }
+                    else {
+                        const uint32_t b0 = ld_l2(&xr[3 * kXReq + ax * 8 + 3]), b1 = ld_l2(&xr[3 * kXReq + ax * 8 + 4]);
+                        x0 = (int)(b0 & 0xffffu); y0 = (int)(b0 >> 16); x1 = (int)(b1 & 0xffffu); y1 = (int)(b1 >> 16);
+                    }
+                    if (hit_since(snap, now, x0, y0, x1, y1) && (st != R_LIGHT || box_tile_hit(snap, x0, y0, x1, y1))) {
                         bool conflict = true;
-                        if (st == R_LIGHTL && (stab.lcnt[ax] & 0xffffu) != 0u) {   // the lists are still in their slot: look at the pixels themselves
-                            const uint32_t lc = stab.lcnt[ax];
+                        const uint32_t lc = st == R_LIGHTL ? stab.lcnt[ax] : st == R_XLIGHTL ? ld_l2(&xr[3 * kXReq + ax * 8 + 5]) : 0u;
+                        if ((lc & 0xffffu) != 0u) {   // the lists are still in their slot: look at the pixels themselves
+                            const size_t gs = st == R_LIGHTL ? img * (size_t)(NW * NS) + ax : (size_t)ld_l2(&xr[3 * kXReq + ax * 8 + 1]);
                             wg_fence();
-                            conflict = examined_hit(b.slist + (img * (size_t)(NW * NS) + ax) * b.gcap, (int)(lc & 0xffffu) - 1 + (int)(lc >> 16), snap);
+                            conflict = examined_hit(b.slist + gs * b.gcap, (int)(lc & 0xffffu) - 1 + (int)(lc >> 16), snap);
                         }
                         if (conflict) {
                             STAT(ST_REDO, 1);
-                            if (lane == 0) { st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }
+                            if (lane == 0) {
+                                if (st == R_XLIGHTL) s_xk[ax] = -1;
+                                st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown));
+                            }
                             DSTAT(ST_DEPTHDN, 1);
                             break;
                         }
                     }
                 }
+                if (st == R_XLIGHTL && lane == 0) s_xk[ax] = -1;
                 bool used_now = false;
                 if (trace) used_now = (c.pw[seedpos[f]] & 3u) != 0u;          // the reference skips it then (:222): no record
                 if (trace && !used_now) {
@@ -1663,18 +1692,20 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
                 continue;
             }
-            if (st == R_STASH) {
+            if (st == R_STASH || st == R_XSTASH) {
                 // ---- a stashed result at the cursor: is it still what the sequential run would get? ----
-                const uint32_t lr = rg.aux[r];
+                const uint32_t ax = rg.aux[r];
+                const size_t lr = st == R_STASH ? img * (size_t)(NW * NS) + ax : (size_t)ld_l2(&xr[3 * kXReq + ax * 8 + 1]);   // the result slot, of this image's waves or of a helper's
                 wg_fence();
-                const double pv = b.pend[(img * (size_t)(NW * NS) + lr) * 24 + (lane < 24 ? lane : 0)];
+                if (st == R_XSTASH && lane == 0) s_xk[ax] = -1;                   // (whatever happens below, the request is over)
+                const double pv = b.pend[lr * 24 + (lane < 24 ? lane : 0)];
                 const double logNFA = rl(pv, 12);
                 const int outcome = (int)rl(pv, 14), num0 = (int)rl(pv, 15), num = (int)rl(pv, 16), m_cnt = (int)rl(pv, 17);
                 const int x0 = (int)rl(pv, 18), y0 = (int)rl(pv, 19), x1 = (int)rl(pv, 20), y1 = (int)rl(pv, 21);
                 const int snap = (int)rl(pv, 23);
                 const long long pk3 = (long long)rl(pv, 22);
                 const int st_n1 = (int)(pk3 % 32768ll) - 1, st_n2 = (int)((pk3 / 32768ll) % 32768ll);
-                const uint32_t* st_list = b.slist + (img * (size_t)(NW * NS) + lr) * b.gcap;
+                const uint32_t* st_list = b.slist + lr * b.gcap;
                 const uint32_t* m_src = st_list + (int)(pk3 / (32768ll * 32768ll));
                 if ((c.pw[seedpos[f]] & 3u) != 0u) {       // an earlier seed marked the pixel meanwhile: the reference skips it (:222)
                     STAT(ST_DISCARD, 1);
@@ -1698,7 +1729,130 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
             break;
         }
+        if (xr && lane == 0) st_l2(&xr[1], (uint32_t)lds_ld(&s_commit));     // (helpers free their result slots behind the cursor)
+#ifdef LSD_REGION_MILESTONES
+        if (lane == 0 && b.stats) {   // developer experiment: when the cursor passed 1/16, 1/8, 1/4, 1/2 of the seeds
+            const int fc = lds_ld(&s_commit);
+            for (int m = 0; m < 4; m++)
+                if (fc >= (nseeds >> (4 - m)) && b.stats[img * kStatWords + 24 + m] == 0) b.stats[img * kStatWords + 24 + m] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+        }
+#endif
         if (lane == 0) lds_st(&s_lock, 0);
+    };
+
+    // ---- Help from other workgroups ----
+    // The batch ends with its heaviest images: long sparse structures regrown from hundreds of seeds, millisecond evaluations that
+    // are independent of one another, on one CU each while the CUs that have finished their images idle.  So a workgroup whose
+    // image is done -- once every workgroup of the launch has started -- turns its wavefronts into HELPERS (the loop below, second
+    // half): each attaches itself to an image that has asked for help, takes seeds that wait for a full evaluation from that
+    // image's request table in HBM, evaluates them speculatively against that image's arrays with its own workspace, and answers
+    // with what a local evaluation publishes: lists and record in the helper's own result slot, the rest in an 8-word message.
+    // The owner's cursor validates and commits such an answer exactly like a local result, so nothing of the order of decisions
+    // changes.  What crosses CUs goes through L2 (agent-scope atomics) behind release / acquire fences: bans and their epoch from
+    // the owner to the helper, lists and records back.  A request nobody has taken when the cursor reaches it is taken back.
+    auto xlock = [&]() -> bool {
+        int got = 0;
+        if (lane == 0) got = atomicCAS(&s_xlock, 0, 1) == 0 ? 1 : 0;
+        return __builtin_amdgcn_readfirstlane(got) != 0;
+    };
+    auto xunlock = [&]() { wg_fence(); if (lane == 0) lds_st(&s_xlock, 0); };
+    // takes the answers that have arrived into the ring; learns how many helpers the image has and tells them its backlog
+    auto xpoll = [&]() -> bool {
+        if (!xlock()) return false;
+        const int kx = lane < kXReq ? s_xk[lane] : -1;
+        const uint32_t fl = kx >= 0 ? ld_l2(&xr[2 * kXReq + lane]) : 0u;
+        const bool ans = kx >= 0 && fl == (uint32_t)(kx + 1);
+        const unsigned long long am = ballot64(ans);
+        if (am) {
+            agent_acquire();                               // the answer, and the lists and the record behind it
+            if (ans) {
+                const uint32_t* m = xr + 3 * kXReq + lane * 8;         // (slot, box and list sizes stay there until the cursor comes by)
+                const uint32_t res = ld_l2(&m[0]), sn = ld_l2(&m[2]);
+                const int r = kx & (RW - 1);
+                rg.snap[r] = (uint16_t)sn; rg.aux[r] = (uint32_t)lane;
+                st_l2(&xr[2 * kXReq + lane], 0u);
+                s_xk[lane] = (res == (uint32_t)R_SKIP || res == (uint32_t)R_REDO) ? -1 : -2;
+                st_st(&rg.state[r], (int)res);             // (a release: after the table entries)
+            }
+            if (lane == 0) atomicSub(&s_xout, __builtin_popcountll(am));
+        }
+        if (lane == 0) {
+            // Help pays where the waves are busy evaluating (an image whose waves wait for the cursor gains nothing from more
+            // evaluators): the share of the last ~100 us the waves spent in the idle path below decides whether the image asks
+            const int tn = (int)__builtin_amdgcn_s_memtime(), dt = tn - s_xt_last;
+            if (dt > 200000) {
+                const int ic = lds_ld(&s_idlecnt);
+                s_workbound = (long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 10 < (long long)dt * NW ? 1 : 0;   // idle < 10 %
+                s_xc_last = ic; s_xt_last = tn;
+            }
+            const int nbg = s_workbound ? max(lds_ld(&s_nbig), 0) : 0;
+            s_nhelp = (int)ld_l2(&xr[3]);
+            st_l2(&xr[4], (uint32_t)nbg);
+            s_xpub = nbg;
+            if (!s_xreg && nbg >= NW) {                    // more seeds wait for an evaluation than this workgroup has waves: ask for help
+                s_xreg = 1;
+                const uint32_t i = atomicAdd(&xhdr[2], 1u);
+                st_l2(&xhdr[kXHdr + i], (uint32_t)img + 1u);
+            }
+        }
+        xunlock();
+        return am != 0ull;
+    };
+    // the cursor stands on a seed that was given to the helpers: take the answers in; if nobody has taken the request, take it back
+    auto xservice = [&](int f0) -> bool {
+        bool moved = xpoll();
+        const int r = f0 & (RW - 1);
+        if (st_ld(&rg.state[r]) != R_REMOTE || lds_ld(&s_commit) != f0) return true;
+        const int j = (int)rg.aux[r];
+        int won = 0;
+        if (lane == 0) won = atomicCAS(&xr[kXReq + j], (uint32_t)(f0 + 1), 0u) == (uint32_t)(f0 + 1) ? 1 : 0;
+        if (__builtin_amdgcn_readfirstlane(won)) {
+            if (lane == 0) { s_xk[j] = -1; atomicSub(&s_xout, 1); st_st(&rg.state[r], R_REDO); }
+            DSTAT(ST_XRECL, 1);
+            moved = true;
+        }
+        return moved;
+    };
+    // seeds that wait for a full evaluation, the youngest first (the oldest are the local waves'), go to the helpers: at most two
+    // requests per helper wavefront outstanding
+    auto xexport = [&](int f, int lim) {
+        const int nh = lds_ld(&s_nhelp);
+        const int cap = min(kXReq - 4, 2 * nh);
+        if (nh <= 0 || lim <= f || lds_ld(&s_nbig) <= 0 || lds_ld(&s_xout) >= cap) return;
+        if (!xlock()) return;
+        for (int it = 0; it < 4; it++) {
+            if (lds_ld(&s_nbig) <= 0 || lds_ld(&s_xout) >= cap) break;
+            const unsigned long long fm = ballot64(lane < kXReq && s_xk[lane] == -1);
+            if (!fm) break;
+            const int j = __builtin_ctzll(fm);
+            int kb = -1;
+            const int b0 = f & ~3;
+            for (int base = b0 + ((lim - 1 - b0) & ~255); base >= b0 && kb < 0; base -= 256) {
+                const int i0 = base + 4 * lane;
+                const uint32_t x = i0 < lim ? __hip_atomic_load(reinterpret_cast<uint32_t*>(rg.state) + ((i0 & (RW - 1)) >> 2), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+                int last = -1;
+                #pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (((x >> (8 * t)) & 0xffu) == (uint32_t)R_BIG && i0 + t >= f && i0 + t < lim) last = i0 + t;
+                const unsigned long long bm = ballot64(last >= 0);
+                if (bm) kb = __builtin_amdgcn_readlane(last, 63 - __builtin_clzll(bm));
+            }
+            if (kb < 0) break;
+            int won = 0;
+            if (lane == 0) {
+                const int r = kb & (RW - 1);
+                won = st_cas(rg.state, r, R_BIG, R_EVAL) ? 1 : 0;       // (nobody reads aux of a record in R_EVAL)
+                if (won) {
+                    atomicSub(&s_nbig, 1); atomicAdd(&s_xout, 1);
+                    rg.aux[r] = (uint32_t)j; s_xk[j] = kb;
+                    st_st(&rg.state[r], R_REMOTE);
+                    st_l2(&xr[kXReq + j], (uint32_t)(kb + 1));
+                }
+            }
+            if (!__builtin_amdgcn_readfirstlane(won)) break;
+            STAT(ST_XEXP, 1);
+        }
+        xunlock();
     };
 
     // Result slots of this wave: slot s holds the lists (and, for a result that marks usedMap, the record in pend[]) of
@@ -1739,14 +1893,18 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done
     bool pend_spec = false;
     int nwait = 0;                                          // consecutive looks that found nothing to do (watchdog)
+    long long xlast = 0;                                    // when this wave last looked at the help protocol
     while (true) {
+        int k = -1, slot = 0;
+        bool spec = false;
         if (adv) {
             // (the cursor is worth a look only when the record it stands on is finished)
             const int f0 = lds_ld(&s_commit);
             const int s0 = f0 < nseeds ? st_ld(&rg.state[f0 & (RW - 1)]) : R_EMPTY;
             LT(ST_TSELECT);
-            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH) advance();
             adv = false;
+            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH || s0 == R_XLIGHTL || s0 == R_XSTASH) advance();
+            else if (s0 == R_REMOTE) { if (xservice(f0)) adv = true; }
             LT(ST_TCOMMIT);
         }
         LT(ST_TSELECT);
@@ -1758,6 +1916,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             // ---- feed the idle groups.  Between chunks (the seeds of a chunk are nobody else's) a wave first looks for a full
             //      evaluation to claim; it starts it when the groups still at work have finished ----
             f = lds_ld(&s_commit);
+            if (xr && !ch_pend && (lds_ld(&s_nbig) >= NW / 2 || lds_ld(&s_xout) > 0 || lds_ld(&s_xpub) > 0)) {
+                // (at most every ~10 us per wave: a look costs an L2 round trip)
+                const long long tn = (long long)__builtin_amdgcn_s_memtime();
+                if (tn - xlast > 20000) { xlast = tn; if (xpoll()) adv = true; }
+            }
             if (!ch_pend && pend_k < 0) {
                 const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
                 if (stf == R_REDO || stf == R_BIG) {
@@ -1771,7 +1934,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (won) { pend_k = f; pend_spec = false; }
                 }
                 const unsigned long long freem = ballot64(lane < NS && slot_k_l < f);
-                if (pend_k < 0 && freem != 0ull && __builtin_popcountll(freem) > NS - b.tun_big && lds_ld(&s_nbig) > 0) {   // (tun_big: results a wave may have waiting for the cursor)
+                if (pend_k < 0 && freem != 0ull && __builtin_popcountll(freem) > NS - max(b.tun_big, min(NS, lds_ld(&s_depth) / (16 * NW))) && lds_ld(&s_nbig) > 0) {   // (tun_big: results a wave may have waiting for the cursor)
                     // the oldest seed waiting for a full evaluation: four records per lane and step
                     const int lim = min(min(lds_ld(&s_next), nseeds), f + lds_ld(&s_depth));
                     int kb = -1;
@@ -1798,6 +1961,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                         progress = true;
                     }
                 }
+                if (xr && lds_ld(&s_nhelp) > 0 && lds_ld(&s_workbound)) xexport(f, min(min(lds_ld(&s_next), nseeds), f + lds_ld(&s_depth)));
                 if (pend_k < 0) {
                     // reserve the next chunk of seeds
                     const int old = lds_ld(&s_next);
@@ -1964,8 +2128,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             nwait = 0;
             continue;
         }
-        int k = -1, slot = 0;
-        bool spec = false;
         if (pend_k >= 0) { k = pend_k; spec = pend_spec; slot = pend_slot; pend_k = -1; nwait = 0; }
         else {
             if (progress) { nwait = 0; continue; }
@@ -1996,6 +2158,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             // nothing to do: every slot waits for the cursor, the ring is full, or nothing is left to hand out.  Sleep long
             // enough that the polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
             if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
+            if (xr) { if (lane == 0) atomicAdd(&s_idlecnt, 1); if (lds_ld(&s_xout) > 0) (void)xpoll(); }   // answers of the helpers
             adv = true;                                    // (look at the cursor again before asking for a job)
 #ifdef LSD_REGION_STATS
             {   // why this wave had nothing to do: no result slot for a waiting seed / the ring is full / no seed is left
@@ -2084,19 +2247,168 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         adv = true;
     }
 
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        b.counts[img] = s_abort ? -1 : s_lines;
+    // ---- this image is finished (every seed committed, or given up): results out ----
+    if (wave == 0 && lane == 0) {
+        b.counts[img] = lds_ld(&s_abort) ? -1 : s_lines;
         if (b.nseed) b.nseed[img] = s_ntrace;
     }
     if (b.stats) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
+        if (lane == 0 && wave == 0 && !lds_ld(&s_abort)) { b.stats[img * kStatWords + 45] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15); b.stats[img * kStatWords + 46] = rt_begin; b.stats[img * kStatWords + 47] = (long long)__builtin_amdgcn_s_memrealtime(); }   // (developer record: when the image ran)
         if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth)); }
-        if (lane < ST_COUNT && !s_abort && (sslot(lane) != 11 || kStatSlots == ST_COUNT)) {
+        if (lane < ST_COUNT && !lds_ld(&s_abort) && (sslot(lane) != 11 || kStatSlots == ST_COUNT)) {
             if (lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][sslot(lane)]);
             else atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
         }
+        g_stat[c.wave][sslot(ST_XHELP)] = 0ull;
     }
+    if (!xr) return;
+    if (wave == 0) {
+        agent_release();
+        if (lane == 0) { st_l2(&xr[2], 1u); atomicAdd(&xhdr[1], 1u); }
+    }
+    // While workgroups still wait for a CU this one should make room -- unless an image is so far behind with its evaluations
+    // that a few wavefronts are better spent there (EARLY helpers: at most tun_early workgroups' worth at a time, only for images
+    // with two backlogged seeds per wave of their own, and gone as soon as there is nothing of that kind)
+    bool early = ld_l2(&xhdr[0]) < gridDim.x;
+    if (early) {
+        if (b.tun_early <= 0) return;
+        int ok = 0;
+        if (lane == 0) {
+            if (atomicAdd(&xhdr[3], 1u) >= (uint32_t)(b.tun_early * NW)) atomicSub(&xhdr[3], 1u);
+            else ok = 1;
+        }
+        if (!__builtin_amdgcn_readfirstlane(ok)) return;
+    }
+
+    // ---- ... then help elsewhere: every wavefront on its own (see "Help from other workgroups" above) ----
+    if (lane < NS) slot_k_l = -1;
+    int hx = -1, hj = 0, hidle = 0;                         // image this wave helps (-1: none), request it is answering, looks without work
+    uint32_t* hrec = nullptr;                               // that image's record of the help protocol
+    const uint32_t* cur_seedpos = seedpos;
+    while (true) {
+        int k = -1, slot = 0;
+        if (hx < 0) {
+            // ---- not attached: the image with the largest backlog per wave already working on it ----
+            if (ld_l2(&xhdr[1]) >= gridDim.x) break;   // every image is finished
+            if (early && ld_l2(&xhdr[0]) >= gridDim.x) {   // every workgroup has its CU by now
+                early = false;
+                if (lane == 0) atomicSub(&xhdr[3], 1u);
+            }
+            const int wt = min(min((int)ld_l2(&xhdr[2]), (int)gridDim.x), 4096);
+            uint32_t best = 0u;
+            for (int base = 0; base < wt; base += 64) {
+                const int i = base + lane;
+                uint32_t key = 0u;
+                if (i < wt) {
+                    const uint32_t im1 = ld_l2(&xhdr[kXHdr + i]);
+                    if (im1) {
+                        const uint32_t* rc = b.xq + (size_t)(im1 - 1u) * kXStride;
+                        if (!ld_l2(&rc[2])) {
+                            const uint32_t bl = ld_l2(&rc[4]), nh = ld_l2(&rc[3]);
+                            if (bl >= (early ? 2u * NW : 1u) && nh < (uint32_t)(early ? NW : b.tun_help)) key = ((min(bl * 16u / (nh + NW), 0xffffeu) + 1u) << 12) | (uint32_t)i;
+                        }
+                    }
+                }
+                #pragma unroll
+                for (int o = 32; o; o >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, o));
+                best = max(best, key);
+            }
+            best = (uint32_t)uni((int)best);
+            if (!best) {
+                if (early) { if (lane == 0) atomicSub(&xhdr[3], 1u); break; }
+                for (int t = 0; t < 8; t++) __builtin_amdgcn_s_sleep(127);
+                continue;
+            }
+            const uint32_t im = ld_l2(&xhdr[kXHdr + (best & 4095u)]) - 1u;
+            uint32_t* rc = b.xq + (size_t)im * kXStride;
+            int ok = 0;
+            if (lane == 0) {
+                if (atomicAdd(&rc[3], 1u) >= (uint32_t)(early ? NW : b.tun_help)) atomicSub(&rc[3], 1u);
+                else ok = 1;
+            }
+            if (!__builtin_amdgcn_readfirstlane(ok)) continue;
+            hx = (int)im; hrec = rc; hidle = 0;
+            cur_seedpos = b.seedpos + (size_t)im * npx;
+            c.mag = b.mag + (size_t)im * npx; c.deg = b.deg + (size_t)im * npx; c.pw = b.pw + (size_t)im * npx;
+            c.epochmap = b.epochmap + (size_t)im * npx; c.sc = b.sc + (size_t)im * npx;
+            c.tep = b.tepoch + (size_t)im * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
+            if (lane == 0) {
+                RCtx& gc = g_ctx[wave];
+                gc.mag = c.mag; gc.deg = c.deg; gc.pw = c.pw; gc.epochmap = c.epochmap; gc.sc = c.sc; gc.tep = c.tep;
+                g_ws[wave].cache_epoch = -1;
+            }
+            wg_fence();
+            continue;
+        }
+        // ---- attached to image hx: a request to answer ----
+        const uint32_t cm = ld_l2(&hrec[1]);
+        const bool xdone = ld_l2(&hrec[2]) != 0u;
+        if (lane < NS && (xdone || slot_k_l < (int)cm)) slot_k_l = -1;          // the cursor has passed these results
+        const unsigned long long freem = ballot64(lane < NS && slot_k_l < 0);
+        if (xdone || (hidle > kHelpIdle && freem == (1ull << NS) - 1ull)) {
+            if (lane == 0) atomicSub(&hrec[3], 1u);
+            hx = -1;
+            continue;
+        }
+        if (__builtin_popcountll(freem) <= NS - b.tun_big) { __builtin_amdgcn_s_sleep(127); continue; }   // (as for local waves)
+        const uint32_t rq = lane < kXReq ? ld_l2(&hrec[kXReq + lane]) : 0u;
+        uint32_t key = (rq != 0u && (rq >> 31) == 0u) ? rq : 0xffffffffu;          // the oldest seed first
+        #pragma unroll
+        for (int o = 32; o; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
+        key = (uint32_t)uni((int)key);
+        if (key == 0xffffffffu) { hidle++; __builtin_amdgcn_s_sleep(127); continue; }
+        const int jj = __builtin_ctzll(ballot64(rq == key));
+        int ok = 0;
+        if (lane == 0) ok = atomicCAS(&hrec[kXReq + jj], key, key | 0x80000000u) == key ? 1 : 0;
+        if (!__builtin_amdgcn_readfirstlane(ok)) continue;
+        k = (int)key - 1; slot = __builtin_ctzll(freem); hj = jj; hidle = 0;
+        if (lane == slot) slot_k_l = k;
+        const uint32_t pp = cur_seedpos[k];
+        const int epoch_snap = (int)ld_l2(&hrec[0]);       // before anything of usedMap is read for this seed ...
+        agent_acquire();                                   // ... (the acquire empties this CU's L1: the bans made up to that epoch are seen)
+        if (epoch_snap != g_ws[wave].cache_epoch) {         // tiles fetched before the last accept may miss its bans
+            invalidate_tiles(c);
+            g_ws[wave].cache_epoch = epoch_snap;
+        }
+        eval_seed(c.wave, pp, 1, slot);
+        const EvalOut& eo = g_eo[wave];
+        const bool skip = eo.skip != 0;
+        const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;
+        const double logNFA = eo.logNFA;
+        const double pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;
+        // the answer: what a local evaluation would have published, with the lists (and the record) in this wave's slot
+        const bool xredo = !skip && outcome >= 2 && eo.redo != 0;
+        const int res = skip ? R_SKIP : outcome <= 1 ? R_XLIGHTL : xredo ? R_REDO : R_XSTASH;
+        const size_t my_slot = (img * NW + wave) * (size_t)NS + slot;
+        if (res == R_XSTASH) {
+            double* P = b.pend + my_slot * 24;
+            if (lane < 12) P[lane] = pv;
+            if (lane == 0) {
+                P[12] = logNFA;
+                P[13] = (double)rec_pk; P[14] = (double)outcome; P[15] = (double)num0; P[16] = (double)num; P[17] = (double)eo.mcnt;
+                P[18] = (double)eo.x0; P[19] = (double)eo.y0; P[20] = (double)eo.x1; P[21] = (double)eo.y1;
+                P[22] = (double)((long long)(eo.precise ? eo.n1 + 1 : 0) + 32768ll * eo.n2 + 32768ll * 32768ll * eo.m_off);
+                P[23] = (double)epoch_snap;
+            }
+        }
+        if (res == R_SKIP || res == R_REDO) { if (lane == slot) slot_k_l = -1; }      // nothing kept in the slot
+        if (lane == 0) {
+            uint32_t* m = hrec + 3 * kXReq + hj * 8;
+            st_l2(&m[0], (uint32_t)res); st_l2(&m[1], (uint32_t)my_slot); st_l2(&m[2], (uint32_t)epoch_snap);
+            if (res == R_XLIGHTL) {
+                st_l2(&m[3], (uint32_t)(eo.x0 & 0xffff) | ((uint32_t)(eo.y0 & 0xffff) << 16));
+                st_l2(&m[4], (uint32_t)(eo.x1 & 0xffff) | ((uint32_t)(eo.y1 & 0xffff) << 16));
+                st_l2(&m[5], eo.precise ? ((uint32_t)(eo.n1 + 1) | ((uint32_t)eo.n2 << 16)) : 0u);
+            }
+        }
+        agent_release();                               // lists, record and message before the flag
+        if (lane == 0) st_l2(&hrec[2 * kXReq + hj], (uint32_t)(k + 1));
+        STAT(ST_XHELP, 1);
+        continue;
+    }
+    // (a helper's count of evaluations done for others goes to its own image's record)
+    if (b.stats && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords) + ST_XHELP, g_stat[c.wave][sslot(ST_XHELP)]);
 }
 
 }  // namespace RVAR

@@ -22,6 +22,8 @@ struct lsd_ctx {
     int num_cus = 256;                 // compute units of the device
     uint32_t id_budget = 0xFFFF0u;     // curMap stamp ids a wave may use per run before it clears its stamps (lsd_debug_set_stamp_budget)
     int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: default), see k_region.hip
+    int tun_help = -1;                                             // helper wavefronts per image (-1: default, 0: none)
+    uint32_t* xq = nullptr;
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     bool prefer4 = false;              // the 8-wave workspace did not fit this device's memory once: batches run on 4 waves per image
     hipStream_t stream = nullptr;      // the context's own stream
@@ -233,6 +235,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->pend, gs * 24));
         HIPCHK(c, re_alloc(&c->order, nn));
+        HIPCHK(c, re_alloc(&c->xq, nn * (size_t)(kXStride + 1) + kXHdr));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
@@ -261,7 +264,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int ma
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order,
+                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order, (void**)&c->xq,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
@@ -334,6 +337,7 @@ int lsd_create(lsd_ctx** out, int device) {
         if ((e = getenv("LSD_REGION_CLAIM"))) c->tun_claim = atoi(e);
         if ((e = getenv("LSD_REGION_FEED"))) c->tun_feed = atoi(e);
         if ((e = getenv("LSD_REGION_BIG"))) c->tun_big = atoi(e);
+        if ((e = getenv("LSD_REGION_HELP"))) c->tun_help = atoi(e);
     }
     *out = c;
     return LSD_OK;
@@ -343,7 +347,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -421,9 +425,13 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         // cursor; it adapts between the two values), idle lane groups per refill, results a wave may have waiting for the cursor
         const int nw = waves_for(c, n);
         b.tun_soft = c->tun_soft > 0 ? c->tun_soft : 48 * nw;
-        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 48 * nw;
+        b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 192 * nw;
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
+        b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
+        { const char* e = getenv("LSD_REGION_EARLY"); b.tun_early = e ? atoi(e) : 0; }
+        { const char* e = getenv("LSD_REGION_STOP"); b.tun_stop = e ? atoi(e) : 0; }
+        b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
     }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
@@ -449,6 +457,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));
         HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), s));
+        if (b.xq) HIPCHK(c, hipMemsetAsync(c->xq, 0, sizeof(uint32_t) * ((size_t)n * (kXStride + 1) + kXHdr), s));
         // 8 wavefronts per image take a whole CU each: worth it up to four images per CU (waves_for); the per-wave workspace
         // (stamps / spill / gcopy: 12 B per scaled pixel and wave) was sized for it by ensure_workspace
         const bool wide = waves_for(c, n) == 8;

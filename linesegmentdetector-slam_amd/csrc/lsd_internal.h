@@ -11,6 +11,13 @@ constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per 
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries
 constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
+// Help across workgroups in the region stage (k_region.hip): a control block of 32-bit words per launch, cleared before it.
+//   per image (kXStride words): [0] accept epoch [1] commit cursor [2] image finished [3] helper wavefronts attached
+//   [4] seeds waiting for a full evaluation; [R, 2R) requests (seed + 1, bit 31: taken by a helper); [2R, 3R) flags of the
+//   answers (seed + 1); [3R, 11R) the answers, 8 words each: result state, result slot, accept epoch of the snapshot, box (2),
+//   list sizes (R = kXReq).  After the n image records (kXHdr words): [0] workgroups started [1] images finished [2] length
+//   of the list of images that ask for help; the list (image + 1) follows.
+constexpr int kXStride = 512, kXReq = 32, kXHdr = 16;
 
 // Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
 // host libm so that they are the very numbers the reference computes (myLSD.cpp:132-133,148-149,207-209).
@@ -66,6 +73,10 @@ struct Buffers {
     int gcap;
     uint32_t id_budget;    // curMap stamp ids per wave and run (k_region.hip: grow())
     int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
+    uint32_t* xq;          // n x kXStride + kXHdr + n : control block of the help across workgroups (see above), null: no help
+    int tun_help;          // helper wavefronts an image may have attached
+    int tun_early;         // workgroups that may help while others still wait for a CU
+    int tun_stop;          // experiments: the seed loop ends after this many potential seeds (0: all)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
     double* recs_scaled;   // n x max_lines x 4 (x1 y1 x2 y2 after the 1/sca rescale)

@@ -28,6 +28,18 @@ for rep in range(reps):
         v = [int(x) for x in v]
         print("   image", i, dict(zip(("s_commit", "s_next", "nseeds", "state_at_cursor", "s_nbig", "s_lock", "pend_k", "wave"), v[40:48])), flush=True)
         print("      per wave (chunk start, pend_k, ch_pend):", [(x & 0xffffffff, (x >> 32) - 1, hex(y)) for x, y in zip(v[24:40:2], v[25:40:2])], flush=True)
+    if os.environ.get("HELPSTATS"):
+        st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
+        tot = np.array([x["cycles_total"] for x in st]) / 1e6
+        t0s = np.array([x["wd_pend"] for x in st], np.float64); t1s = np.array([x["wd_wave"] for x in st], np.float64)
+        # (the counter is per XCD; every XCD has workgroups that started with the launch)
+        cl = np.array([x["wd_lock"] for x in st])          # XCC id
+        b0, e0 = (t0s - t0s.min()) / 1e5, (t1s - t0s.min()) / 1e5      # ms (s_memrealtime: 100 MHz)
+        print("   timeline (ms from the first start): last start %.1f, ends: median %.1f p90 %.1f max %.1f" % (b0.max(), np.median(e0), np.percentile(e0, 90), e0.max()))
+        for i in np.argsort(-e0)[:8]: print("      image %d: start %.1f end %.1f Mcycles %.0f exports %d" % (i, b0[i], e0[i], tot[i], st[i]["help_exports"]))
+        print("      started after 0.1 ms: %d images; their starts: p10 %.1f median %.1f p90 %.1f" % ((b0 > 0.1).sum(), *np.percentile(b0[b0 > 0.1], [10, 50, 90])))
+        print("      per XCD: images, last start, last end:", [(int((cl == x).sum()), int(b0[cl == x].max()), int(e0[cl == x].max())) for x in sorted(set(cl.tolist()))])
+        print("   help: exports %d evals %d | Mcycles per image: mean %.0f max %.0f" % (sum(x["help_exports"] for x in st), sum(x["help_evals"] for x in st), tot.mean(), tot.max()), flush=True)
     cur = (c.tobytes(), lines.cpu().numpy().tobytes())
     if ref is None: ref = cur
     elif cur != ref: print("   DIFFERS from run 0", flush=True)

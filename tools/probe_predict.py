@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Developer experiment: how well do the cycles of the first K seeds of an image predict the cycles of all of them?
+(LSD_REGION_STOP=K ends the seed loop after K potential seeds.)   tools/probe_predict.py K [K ...]"""
+import importlib, os, sys, subprocess, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    sys.path.insert(0, ROOT)
+    import bench, torch
+    lsd = importlib.import_module("linesegmentdetector-slam_amd")
+    maps = bench.load_maps(); n = 512
+    ctx = lsd.Context(0)
+    d = torch.from_numpy(bench.make_batch(maps, n, 2048)).cuda()
+    lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for rep in range(2):
+        ctx.enqueue_device(d.data_ptr(), n, 2048, 2048, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
+    wh = lsd.scaled_size(2048, 2048)
+    st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
+    print(json.dumps({"region": ctx.timings()["region"], "cyc": [x["cycles_total"] for x in st], "seeds": [x["seeds"] for x in st], "grown": [x["grown_px"] for x in st]}))
+    sys.exit(0)
+def run(stop):
+    env = dict(os.environ, LSD_REGION_STOP=str(stop), LSD_REGION_HELP="0")
+    out = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True).stdout
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+full = run(0)
+cf = np.array(full["cyc"], float)
+print("full: region %.1f ms, cycles mean %.0f M max %.0f M; corr(seeds, cycles) %.2f" % (full["region"], cf.mean() / 1e6, cf.max() / 1e6, np.corrcoef(full["seeds"], cf)[0, 1]))
+for K in [int(a) for a in sys.argv[1:]]:
+    p = run(K)
+    cp = np.array(p["cyc"], float)
+    # prediction: the probe's cycles scaled by seeds / K, and a straight-line fit on (probe cycles, seeds)
+    X = np.c_[cp, np.array(full["seeds"], float), np.ones(len(cp))]
+    coef, *_ = np.linalg.lstsq(X, cf, rcond=None)
+    pred = X @ coef
+    top = set(np.argsort(-cf)[:32]); ptop = set(np.argsort(-pred)[:32])
+    print("K %6d: probe region %.1f ms; corr(probe cycles, full) %.2f, fit with seeds %.2f; top-32 overlap %d" % (K, p["region"], np.corrcoef(cp, cf)[0, 1], np.corrcoef(pred, cf)[0, 1], len(top & ptop)))

@@ -1,0 +1,5 @@
+for cfg in "1536 12 24" "1024 8 24" "1536 12 48" "1536 12 0"; do
+  set -- $cfg
+  echo "== soft $1 big $2 help $3"
+  LSD_REGION_HELP=$3 LSD_REGION_SOFT=$1 LSD_REGION_CLAIM=$1 LSD_REGION_BIG=$2 HELPSTATS=1 timeout 120 python tools/hang_probe.py 512 2048 2 2>&1 | grep -v amdgpu.ids | grep -v "      image"
+done
