@@ -11,18 +11,23 @@
 // (== 1)?", and only ACCEPTED lines ever set a pixel to 1 (rejected regions set 2, which stays
 // growable; small/failed regions set nothing).  So the wavefronts of a workgroup evaluate seeds
 // SPECULATIVELY ahead of a commit cursor and commit in seed order:
-//   * a wave takes the next seed (one at a time, whichever wave is free), notes the accept epoch, and evaluates
-//     it with all 64 lanes: grow() (8 frontier pixels x 8 neighbours per batch out of an LDS tile cache of packed
-//     pixel words), rectangle, Refiner incl. its regrow, NFA;
-//   * results that mark nothing are published in an LDS ring, results that mark usedMap are stashed (record +
-//     pixel list in one of the wave's result slots) and committed when the cursor reaches them;
-//   * at its turn a result is valid if its seed is still unused and no pixel it EXAMINED (a member of one of
-//     its grown lists or one of their 8 neighbours) was banned since its snapshot -- accepted pixels carry
-//     their line's epoch (epochmap), the boxes of recently accepted lines are a first filter; an invalid result
-//     is evaluated again at the cursor, where everything earlier is committed;
-//   * commit = mark usedMap (code 3 + epoch, or 2), append the rectangle, advance the cursor.
+//   * seeds are handed out in chunks of 32; every seed has a record in an LDS ring (state byte, snapshot epoch, a result word);
+//   * a wavefront first CLASSIFIES the seeds of its chunk, eight at a time: its eight 8-lane groups each grow one seed's region
+//     out of a 16x16-pixel window in LDS.  Nine regions in ten stay below regThre pixels and end there (nothing to mark, :228);
+//   * the others wait for a FULL evaluation by whichever wave is free: grow() with all 64 lanes (8 frontier pixels x 8
+//     neighbours per batch out of an LDS tile cache of packed pixel words), rectangle, Refiner incl. its regrow, NFA
+//     (eval_seed()); results that mark nothing are published in the ring, results that mark usedMap are stashed (record +
+//     pixel list in one of the wave's result slots in HBM) and committed when the cursor reaches them;
+//   * at its turn a result is valid if its seed is still unused and no MEMBER of its grown lists was banned since its
+//     snapshot -- accepted pixels carry their line's epoch (epochmap), per-tile accept epochs and the boxes of recently
+//     accepted lines are the first filters; an invalid result is evaluated again at the cursor, where everything earlier is
+//     committed;
+//   * commit = mark usedMap (code 3 + epoch, or 2), append the rectangle, advance the cursor (up to 64 records per step);
+//   * how far ahead the waves work adapts (deeper while waves idle, shallower after a redo);
+//   * a workgroup whose image is done lends its wavefronts to images that are still busy evaluating ("Help from other
+//     workgroups" in the kernel): requests and answers through HBM, the owner's cursor commits.
 // The committed sequence of decisions is therefore exactly the sequential one (DESIGN.md section 4 has the
-// measurements behind every choice, and the variants that were tried and dropped).
+// measurements behind every choice, DESIGN_NOTES.md the variants that were tried and dropped).
 // Inside a wavefront the lanes cooperate where the order of evaluation can be kept:
 //   * region growing: candidates are classified against the ESTIMATED sum vector of the region with a rigorous
 //     margin, the exact fp64 angle sums (reference order = list order) are caught up lazily from the list;
@@ -1782,7 +1787,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             const int tn = (int)__builtin_amdgcn_s_memtime(), dt = tn - s_xt_last;
             if (dt > 200000) {
                 const int ic = lds_ld(&s_idlecnt);
-                s_workbound = (long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 10 < (long long)dt * NW ? 1 : 0;   // idle < 10 %
+                s_workbound = (long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 100 < (long long)dt * NW * b.tun_wb ? 1 : 0;   // idle < tun_wb %
                 s_xc_last = ic; s_xt_last = tn;
             }
             const int nbg = s_workbound ? max(lds_ld(&s_nbig), 0) : 0;

@@ -76,6 +76,7 @@ struct Buffers {
     uint32_t* xq;          // n x kXStride + kXHdr + n : control block of the help across workgroups (see above), null: no help
     int tun_help;          // helper wavefronts an image may have attached
     int tun_early;         // workgroups that may help while others still wait for a CU
+    int tun_wb;            // an image asks for help while its waves idle less than this share of the time (percent)
     int tun_stop;          // experiments: the seed loop ends after this many potential seeds (0: all)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
