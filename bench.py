@@ -258,7 +258,8 @@ def main():
             except Exception:
                 traffic = None
         # per-image cycles of the region stage (s_memtime, read after the timed region): the batch time is its heaviest images
-        cyc = np.array([ctx.fetch(i, lsd.DBG_STATS, (w, h))["cycles_total"] for i in range(n)], np.float64)
+        stats = [ctx.fetch(i, lsd.DBG_STATS, (w, h)) for i in range(n)]
+        cyc = np.array([x["cycles_total"] for x in stats], np.float64)
         nb_mean = float(np.mean([ctx.fetch(i, lsd.DBG_NB, (w, h)) for i in range(0, n, max(1, n // 32))]))
         # SURVEY 8d algorithmic bytes of the whole path per image: K1 W*H + 8wh, K2 25wh, K3 8wh + 12 nb, K5 W*H (K4: latency-bound, none)
         alg_img = 2.0 * size * size + (8 + 25 + 8) * w * h + 12.0 * nb_mean
@@ -287,7 +288,10 @@ def main():
             "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (step_s * 1e3),
                                 "Mpix_per_s": n * size * size / 1e6 / (reg_ms * 1e-3), "lines_per_s": float(d_counts.sum().item()) / (reg_ms * 1e-3),
                                 "bound": "serial dependence per image (no HBM / MFMA roofline applies): DESIGN.md section 4",
-                                "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean())}},
+                                "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean())},
+                                # full evaluations of the last step that wavefronts of finished workgroups did for other images
+                                "help_across_workgroups": {"evaluations": int(sum(x["help_evals"] for x in stats)),
+                                                           "images_helped": int(sum(1 for x in stats if x["help_exports"] > 0))}},
             "roofline_pipeline": {"bound": "hbm", "algorithmic_bytes_per_step": alg_img * n, "achieved": alg_img * n_total / step_s / 1e9,
                                   "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg_img * n_total / step_s / 1e9 / (HBM_PEAK_GBS * world),
                                   "note": "SURVEY 8d algorithmic bytes of the whole path (K1+K2+K3+K5; %.1f MB per image) over the step time" % (alg_img / 1e6)},

@@ -1392,7 +1392,6 @@ enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5
 constexpr int kHelpIdle = 50;             // looks without a request after which a helper wavefront leaves an image
 constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
 constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
-constexpr int kDepthUp = 32, kDepthDown = 96;   // steps of the adaptive look-ahead (see the seed loop)
 
 constexpr int SCAP = 16;                  // list entries of a small-region group
 
@@ -1506,6 +1505,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     // to do within it, and shrinks when a speculative result is redone or discarded at the cursor.  Ring slots are reused no
     // sooner than 128 commits later.
     const int depth_min = min(max(b.tun_soft, 2 * CH), RW - 128), depth_max = min(max(b.tun_claim, depth_min), RW - 128);
+    const int kDepthUp = b.tun_up, kDepthDown = b.tun_down;   // steps of the adaptive look-ahead
     const int kFeed = min(max(b.tun_feed, 1), 8);           // idle groups that make a wave fetch the windows of its next seeds (a memory round trip)
     // box overlap of record-style boxes against the lines accepted in epochs [snap, now)
     auto hit_since = [&](int snap, int now, int x0, int y0, int x1, int y1) -> bool {
@@ -1805,7 +1805,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     };
     // the cursor stands on a seed that was given to the helpers: take the answers in; if nobody has taken the request, take it back
     auto xservice = [&](int f0) -> bool {
-        bool moved = xpoll();
+        bool moved = false;
         const int r = f0 & (RW - 1);
         if (st_ld(&rg.state[r]) != R_REMOTE || lds_ld(&s_commit) != f0) return true;
         const int j = (int)rg.aux[r];
@@ -1899,9 +1899,16 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     bool pend_spec = false;
     int nwait = 0;                                          // consecutive looks that found nothing to do (watchdog)
     long long xlast = 0;                                    // when this wave last looked at the help protocol
+    int xwant = 0;                                          // 1: look at the help protocol, 2: ... and the cursor stands on a seed given away
     while (true) {
         int k = -1, slot = 0;
         bool spec = false;
+        if (xwant) {                                       // (the one place the protocol is looked at from: it is a lot of code)
+            bool moved = xpoll();
+            if (xwant == 2) moved = xservice(lds_ld(&s_commit)) || moved;
+            xwant = 0;
+            if (moved) adv = true;
+        }
         if (adv) {
             // (the cursor is worth a look only when the record it stands on is finished)
             const int f0 = lds_ld(&s_commit);
@@ -1909,7 +1916,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             LT(ST_TSELECT);
             adv = false;
             if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH || s0 == R_XLIGHTL || s0 == R_XSTASH) advance();
-            else if (s0 == R_REMOTE) { if (xservice(f0)) adv = true; }
+            else if (s0 == R_REMOTE) xwant = 2;
             LT(ST_TCOMMIT);
         }
         LT(ST_TSELECT);
@@ -1924,7 +1931,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (xr && !ch_pend && (lds_ld(&s_nbig) >= NW / 2 || lds_ld(&s_xout) > 0 || lds_ld(&s_xpub) > 0)) {
                 // (at most every ~10 us per wave: a look costs an L2 round trip)
                 const long long tn = (long long)__builtin_amdgcn_s_memtime();
-                if (tn - xlast > 20000) { xlast = tn; if (xpoll()) adv = true; }
+                if (tn - xlast > 20000) { xlast = tn; xwant = max(xwant, 1); }
             }
             if (!ch_pend && pend_k < 0) {
                 const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
@@ -2163,7 +2170,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             // nothing to do: every slot waits for the cursor, the ring is full, or nothing is left to hand out.  Sleep long
             // enough that the polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
             if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
-            if (xr) { if (lane == 0) atomicAdd(&s_idlecnt, 1); if (lds_ld(&s_xout) > 0) (void)xpoll(); }   // answers of the helpers
+            if (xr) { if (lane == 0) atomicAdd(&s_idlecnt, 1); if (lds_ld(&s_xout) > 0) xwant = max(xwant, 1); }   // answers of the helpers
             adv = true;                                    // (look at the cursor again before asking for a job)
 #ifdef LSD_REGION_STATS
             {   // why this wave had nothing to do: no result slot for a waiting seed / the ring is full / no seed is left

@@ -431,6 +431,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
         { const char* e = getenv("LSD_REGION_EARLY"); b.tun_early = e ? atoi(e) : 0; }
         { const char* e = getenv("LSD_REGION_WB"); b.tun_wb = e ? atoi(e) : 10; }
+        { const char* e = getenv("LSD_REGION_UP"); b.tun_up = e ? atoi(e) : 32; e = getenv("LSD_REGION_DOWN"); b.tun_down = e ? atoi(e) : 96; }
         { const char* e = getenv("LSD_REGION_STOP"); b.tun_stop = e ? atoi(e) : 0; }
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
     }

@@ -77,6 +77,7 @@ struct Buffers {
     int tun_help;          // helper wavefronts an image may have attached
     int tun_early;         // workgroups that may help while others still wait for a CU
     int tun_wb;            // an image asks for help while its waves idle less than this share of the time (percent)
+    int tun_up, tun_down;  // steps of the adaptive look-ahead (seeds): up when a wave finds nothing to do, down on a redo / discard
     int tun_stop;          // experiments: the seed loop ends after this many potential seeds (0: all)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)

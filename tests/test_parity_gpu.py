@@ -751,6 +751,42 @@ def test_feature_scan_batch_matches_oracle(lsdmod, ctx, oracle):
     assert np.array_equal(one["scanImPoint"], got[5]["scanImPoint"]) and one["linesInfo"].tobytes() == got[5]["linesInfo"].tobytes()
 
 
+@pytest.mark.parametrize("waves", [8, 4])
+def test_help_across_workgroups_changes_nothing(waves, maps, lsdmod, oracle):
+    """One of the heaviest bench images in a launch with 23 copies of a light one: the workgroups of the light images finish
+    early and their wavefronts evaluate seeds of the heavy image (k_region.hip, "Help from other workgroups").  The counters say
+    that they did; lines, line records and lineIm are those of the oracle and, byte for byte, those of a context with the help
+    switched off (LSD_REGION_HELP=0, read when a context is created)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    heavy, light = bench.make_image(maps, 187, 2048), bench.make_image(maps, 0, 2048)
+    batch = np.stack([heavy] + [light] * 23)
+    wh = lsdmod.scaled_size(2048, 2048)
+    res = {}
+    for help_ in ("24", "0"):
+        old = os.environ.get("LSD_REGION_HELP")
+        os.environ["LSD_REGION_HELP"] = help_
+        try:
+            c = lsdmod.Context(0)
+        finally:
+            if old is None: del os.environ["LSD_REGION_HELP"]
+            else: os.environ["LSD_REGION_HELP"] = old
+        c.set_region_waves(waves)
+        lines, offs, ims = c.run_batch(batch.copy())
+        st = [c.fetch(i, lsdmod.DBG_STATS, wh) for i in range(len(batch))]
+        res[help_] = (lines.tobytes(), offs.tobytes(), ims.tobytes(), st[0]["help_exports"], sum(x["help_evals"] for x in st))
+        if help_ == "24":
+            for j in (0, 1):
+                ref = oracle.lsd(batch[j].copy())
+                assert offs[j + 1] - offs[j] == len(ref["lines"])
+                assert_lines_close(lines[offs[j]:offs[j + 1]], ref["lines"])
+                assert np.array_equal(ims[j], ref["lineIm"])
+        c.close()
+    assert res["24"][:3] == res["0"][:3]
+    assert res["0"][3] == 0 and res["0"][4] == 0
+    assert res["24"][3] > 20 and res["24"][4] > 20, res["24"][3:]      # (hundreds on an idle device)
+
+
 def test_region_stage_variants_agree(maps, lsdmod, ctx, oracle):
     """The region stage exists with 4 and with 8 wavefronts per image (chosen by batch size): same lines, same usedMap."""
     crop = lambda a: np.ascontiguousarray(a[:600, :1600])
