@@ -1573,6 +1573,55 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     // Commits a result that marks usedMap (accepted line: code 3 + epoch; rejected region: code 2), at the cursor, under
     // the cursor lock: pv = lane j < 12: field j of the rectangle (structRec order); m_src: the pixels to mark (null: this
     // wave's own last grow).
+    // A line has just been accepted (seed k, box mb).  A finished result further ahead that it invalidates would be found
+    // invalid when the cursor reaches it and evaluated again THERE, with every other wave waiting (images with many lines on
+    // the same structures spent 45 % of their time in such evaluations).  Found now, it goes back to the seeds that wait for a
+    // full evaluation and is redone by whichever wave is free while the cursor works its way towards it.  (Called by the wave
+    // that owns the cursor; nobody else touches a finished record.)
+    auto requeue_ahead = [&](int k, const Box& mb) {
+        const int lim = min(lds_ld(&s_next), nseeds);
+        const int now = lds_ld(&s_epoch);
+        for (int base = k + 1; base < lim; base += 64) {
+            const int idx = base + lane;
+            const int rr = idx & (RW - 1);
+            const int stl = idx < lim ? st_ld(&rg.state[rr]) : R_EMPTY;
+            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+            if (stl == R_LIGHT) {
+                const uint32_t ax = rg.aux[rr], sp = seedpos[idx];
+                const int sxp = (int)(sp % (uint32_t)w), syp = (int)(sp / (uint32_t)w);
+                x0 = sxp + (int)(ax & 63u) - 32; y0 = syp + (int)((ax >> 6) & 63u) - 32;
+                x1 = sxp + (int)((ax >> 12) & 63u) - 32; y1 = syp + (int)((ax >> 18) & 63u) - 32;
+            } else if (stl == R_LIGHTL) {
+                const uint32_t ax = rg.aux[rr];
+                x0 = stab.box[ax][0]; y0 = stab.box[ax][1]; x1 = stab.box[ax][2]; y1 = stab.box[ax][3];
+            } else if (stl == R_STASH) {
+                const double* P = b.pend + (img * (size_t)(NW * NS) + rg.aux[rr]) * 24;
+                x0 = (int)P[18]; y0 = (int)P[19]; x1 = (int)P[20]; y1 = (int)P[21];
+            }
+            unsigned long long hm = ballot64(!(mb.x1 < x0 || mb.x0 > x1 || mb.y1 < y0 || mb.y0 > y1) && x1 >= x0);
+            while (hm) {
+                const int l = __builtin_ctzll(hm);
+                hm &= hm - 1ull;
+                const int st1 = __builtin_amdgcn_readlane(stl, l), r1 = (base + l) & (RW - 1);
+                const uint32_t ax1 = rg.aux[r1];
+                const int snap = now - ((now - (int)rg.snap[r1]) & 0xffff);
+                bool conflict = true;
+                if (st1 == R_LIGHT) {
+                    conflict = box_tile_hit(snap, __builtin_amdgcn_readlane(x0, l), __builtin_amdgcn_readlane(y0, l), __builtin_amdgcn_readlane(x1, l), __builtin_amdgcn_readlane(y1, l));
+                } else {
+                    const size_t gs = img * (size_t)(NW * NS) + ax1;
+                    int n = -1;
+                    if (st1 == R_LIGHTL) { const uint32_t lc = stab.lcnt[ax1]; if (lc & 0xffffu) n = (int)(lc & 0xffffu) - 1 + (int)(lc >> 16); }
+                    else { const long long pk3 = (long long)b.pend[gs * 24 + 22]; const int n1 = (int)(pk3 % 32768ll) - 1; if (n1 >= 0) n = n1 + (int)((pk3 / 32768ll) % 32768ll); }
+                    if (n >= 0) conflict = examined_hit(b.slist + gs * b.gcap, n, snap);
+                }
+                if (conflict) {
+                    if (lane == 0) { st_st(&rg.state[r1], R_BIG); atomicAdd(&s_nbig, 1); }
+                    DSTAT(ST_DEPTHUP, 1);
+                }
+            }
+        }
+    };
     auto commit_marks = [&](int k, int num0, int fnum, int outcome, double logNFA, double pv, const uint32_t* m_src, int m_cnt) {
         write_trace(k, num0, fnum, outcome, logNFA);
         if (outcome == 2) {                                                          // :242-250
@@ -1596,6 +1645,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             }
             invalidate_tiles(c);                          // this wave's cached ban flags are stale now
             g_ws[wave].cache_epoch = -1;
+            wg_fence();
+            if (b.tun_requeue) requeue_ahead(k, mb);
         }
         wg_fence();                                       // marks + ring visible before the cursor moves
     };
@@ -1682,7 +1733,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                                 if (st == R_XLIGHTL) s_xk[ax] = -1;
                                 st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown));
                             }
-                            DSTAT(ST_DEPTHDN, 1);
                             break;
                         }
                     }
@@ -1724,7 +1774,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                     if (conflict) {
                         STAT(ST_REDO, 1);
                         if (lane == 0) { st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }     // evaluate again; everything earlier is committed now
-                        DSTAT(ST_DEPTHDN, 1);
                         break;
                     }
                 }
@@ -1931,7 +1980,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (xr && !ch_pend && (lds_ld(&s_nbig) >= NW / 2 || lds_ld(&s_xout) > 0 || lds_ld(&s_xpub) > 0)) {
                 // (at most every ~10 us per wave: a look costs an L2 round trip)
                 const long long tn = (long long)__builtin_amdgcn_s_memtime();
-                if (tn - xlast > 20000) { xlast = tn; xwant = max(xwant, 1); }
+                if (tn - xlast > b.tun_xpoll) { xlast = tn; xwant = max(xwant, 1); }
             }
             if (!ch_pend && pend_k < 0) {
                 const int stf = f < nseeds ? st_ld(&rg.state[f & (RW - 1)]) : R_EMPTY;
@@ -2166,7 +2215,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 const int d = lds_ld(&s_depth);
                 if (d < depth_max) lds_st(&s_depth, min(d + kDepthUp, depth_max));
             }
-            DSTAT(ST_DEPTHUP, nwait == 1 ? 1 : 0);
             // nothing to do: every slot waits for the cursor, the ring is full, or nothing is left to hand out.  Sleep long
             // enough that the polling of the waiting waves does not take issue slots from the evaluation the cursor waits for
             if (lds_ld(&s_commit) == f) __builtin_amdgcn_s_sleep(LSD_REGION_WAIT_SLEEP);
@@ -2203,6 +2251,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
         const double pv = lane < 12 ? reinterpret_cast<const double*>(&g_ws[wave].rec)[lane] : 0.0;   // lane j < 12: field j of the result's rectangle (structRec order)
 
         // ---- hand the result over ----
+#ifdef LSD_REGION_STATS
+        if (!spec) DSTAT(ST_DEPTHDN, NOW() - tl);          // (time of the evaluations AT the cursor: everybody else may be waiting for them)
+#endif
         LT(ST_TEVAL);
         if (!spec) {
             // ---- evaluated at the cursor (k == s_commit, record R_BUSY: nobody else can commit): commit right away ----

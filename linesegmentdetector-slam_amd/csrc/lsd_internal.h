@@ -78,6 +78,8 @@ struct Buffers {
     int tun_early;         // workgroups that may help while others still wait for a CU
     int tun_wb;            // an image asks for help while its waves idle less than this share of the time (percent)
     int tun_up, tun_down;  // steps of the adaptive look-ahead (seeds): up when a wave finds nothing to do, down on a redo / discard
+    int tun_requeue;       // results invalidated by a line are queued for another evaluation when the line is accepted (1) or found at the cursor (0)
+    int tun_xpoll;         // shader clocks between two looks of a wave at the help protocol
     int tun_stop;          // experiments: the seed loop ends after this many potential seeds (0: all)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)
