@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, map1 targets, single-image latency, copy ceiling): what the profiling passes use")
     ap.add_argument("--no-lineim", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
+    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight: step i runs on context / stream i %% depth, so that the tail of one step's region stage "
+                    "(a few images on a CU each) overlaps the head of the next one's; 1 = one step at a time")
     a = ap.parse_args()
 
     import torch
@@ -194,21 +196,35 @@ def main():
     host = make_batch(maps, n, size, first)
     d_maps = torch.from_numpy(host).to(dev)
     del host
-    d_lines = torch.zeros((n, a.max_lines, 10), dtype=torch.int64, device=dev)
-    d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_ims = None if a.no_lineim else torch.zeros((n, size, size), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx.reserve(n, size, size)
+    # Steps in flight (--pipeline): every slot has its own context (= workspace), stream and output buffers; all read the same
+    # resident input.  With several steps in flight the help across workgroups is off: the next step's workgroups take the
+    # CUs a step's last images leave idle, helpers would hold them (include/lsd_hip.h, lsd_set_region_help).
+    depth = max(1, a.pipeline)
+    ctxs = [ctx] + [lsd.Context(local) for _ in range(depth - 1)]
+    outs = [(torch.zeros((n, a.max_lines, 10), dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+             None if a.no_lineim else torch.zeros((n, size, size), dtype=torch.uint8, device=dev)) for _ in range(depth)]
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    d_lines, d_counts, d_ims = outs[0]
+    stream = tstreams[0].cuda_stream
+    for c_ in ctxs:
+        c_.reserve(n, size, size)
+        if depth > 1:
+            c_.set_region_help(0)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
     cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)
 
-    def step(collect):
-        ctx.enqueue_device(d_maps.data_ptr(), n, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(),
-                           d_line_ims=None if d_ims is None else d_ims.data_ptr(), stream=stream)
-        res = ldist.gather_line_lists(d_lines, d_counts, n_total, dst=0, cap_rows=cap_rows, dense=False) if use_dist else None
-        if collect:                                        # HIP events recorded on the launch stream by the library
-            for k, v in ctx.timings().items():
+    def step(i, collect):
+        j = i % depth
+        l_, c_, im_ = outs[j]
+        ctxs[j].enqueue_device(d_maps.data_ptr(), n, size, size, l_.data_ptr(), a.max_lines, c_.data_ptr(),
+                               d_line_ims=None if im_ is None else im_.data_ptr(), stream=tstreams[j].cuda_stream)
+        res = None
+        if use_dist:
+            with torch.cuda.stream(tstreams[j]):
+                res = ldist.gather_line_lists(l_, c_, n_total, dst=0, cap_rows=cap_rows, dense=False)
+        if collect:                                        # HIP events recorded on the launch stream by the library (this waits for the step)
+            for k, v in ctxs[j].timings().items():
                 kt[k] += v
         return res
 
@@ -217,24 +233,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step(False)
+    for i in range(a.warmup):
+        step(i, False)
     barrier()
     t0 = time.perf_counter()
     res = None
-    for _ in range(a.steps):
-        res = step(True)
+    for i in range(a.steps):
+        res = step(i, depth == 1)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    nl = d_counts.sum().to(torch.float64).reshape(1)
+    last = outs[(a.steps - 1) % depth]
+    # One step at a time, after the timed region when that ran with several in flight: the per-kernel figures (inside an
+    # overlapped region a launch's HIP events also time its wait for a CU) and the step time of a single batch, help on.
+    un_steps, un_dt = a.steps, dt
+    if depth > 1:
+        ctx.set_region_help(-1)
+        un_steps = min(a.steps, 5)
+        depth_saved, depth = depth, 1
+        step(0, False); step(0, False)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(un_steps):
+            step(0, True)
+        torch.cuda.synchronize()
+        barrier()
+        un_dt = time.perf_counter() - t1
+        depth = depth_saved
+    tmax = torch.tensor([dt, un_dt], dtype=torch.float64, device=dev)
+    nl = last[1].sum().to(torch.float64).reshape(1)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nl, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
+    dt, un_dt = float(tmax[0].item()), float(tmax[1].item())
     total_lines = float(nl.item())
-    overflow = int((d_counts > a.max_lines).sum().item())
+    overflow = int((last[1] > a.max_lines).sum().item())
 
     if rank == 0:
         if use_dist:                                       # the gathered result of the last step: every line arrived, nothing overflowed
@@ -242,7 +275,8 @@ def main():
             assert int(cnts.sum().item()) == int(total_lines) and not bool(over.any().item()), "gather_line_lists lost lines"
         step_s = dt / a.steps
         mpix = n_total * size * size / 1e6
-        grad_ms = kt["gradient"] / a.steps
+        grad_ms = kt["gradient"] / un_steps
+        un_step_s = un_dt / un_steps
         grad_bytes = GRAD_BYTES_PER_PX * w * h * n
         achieved = grad_bytes / (grad_ms * 1e-3) / 1e9 if grad_ms > 0 else 0.0
         traffic, traffic_all, traffic_src = None, {}, None
@@ -263,7 +297,7 @@ def main():
         nb_mean = float(np.mean([ctx.fetch(i, lsd.DBG_NB, (w, h)) for i in range(0, n, max(1, n // 32))]))
         # SURVEY 8d algorithmic bytes of the whole path per image: K1 W*H + 8wh, K2 25wh, K3 8wh + 12 nb, K5 W*H (K4: latency-bound, none)
         alg_img = 2.0 * size * size + (8 + 25 + 8) * w * h + 12.0 * nb_mean
-        reg_ms = kt["region"] / a.steps
+        reg_ms = kt["region"] / un_steps
         out = {
             "metric": "Mpixels/sec LSD (grad+grow+NFA)", "value": mpix / step_s, "unit": "Mpix/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
@@ -273,11 +307,17 @@ def main():
                                        a.batch, size, size, "per GPU" if a.scaling == "weak" else "in total, split over the GPUs"),
                        "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU",
-                       "rccl_gather_in_step": bool(use_dist)},
+                       "rccl_gather_in_step": bool(use_dist),
+                       "steps_in_flight": depth},
+            # the timed region keeps `steps_in_flight` steps in flight (one context, stream and set of output buffers each);
+            # `one_step_at_a_time` is the same step run alone, measured right after it -- the source of every per-kernel figure below
+            "one_step_at_a_time": {"steps": un_steps, "ms_per_step": un_step_s * 1e3, "value": mpix / un_step_s, "unit": "Mpix/s",
+                                   "note": "a batch alone on the GPU, help across workgroups on; kernel_ms, roofline and dominant_kernel are from these steps "
+                                           "(HIP events of a launch inside an overlapped region also time its wait for a CU)" if depth > 1 else "identical to the timed region"},
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
-            "kernel_ms": {k: v / a.steps for k, v in kt.items()},
+            "kernel_ms": {k: v / un_steps for k, v in kt.items()},
             # informational: every kernel's HBM traffic (PMC, profiles/traffic_latest.json) over its live launch time
-            "kernel_hbm_GBs": {k: traffic_all["k_" + k] / (kt[k] / a.steps * 1e-3) / 1e9
+            "kernel_hbm_GBs": {k: traffic_all["k_" + k] / (kt[k] / un_steps * 1e-3) / 1e9
                                for k in ("gauss", "gradient", "sort", "region", "lines") if ("k_" + k) in traffic_all and kt[k] > 0},
             # the kernel north_star prices: the gradient pass, algorithmic bytes over its HIP-event launch time of THIS run
             "roofline": {"kernel": "k_gradient", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -285,7 +325,7 @@ def main():
                          "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_ms,
                          "note": "k_gradient is the pass north_star prices, not the dominant kernel: see dominant_kernel / roofline_pipeline"},
             # ... and the whole truth next to it: the step is the region stage, a serial-latency / instruction-issue bound kernel
-            "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (step_s * 1e3),
+            "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (un_step_s * 1e3),
                                 "Mpix_per_s": n * size * size / 1e6 / (reg_ms * 1e-3), "lines_per_s": float(d_counts.sum().item()) / (reg_ms * 1e-3),
                                 "bound": "serial dependence per image (no HBM / MFMA roofline applies): DESIGN.md section 4",
                                 "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean())},
@@ -316,7 +356,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
 
 
 def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total):

@@ -189,6 +189,12 @@ int lsd_set_trace(lsd_ctx *ctx, int on);
  * image, images taken heaviest first).  0 (default) picks 8 while the batch has at most four images per CU (the step is
  * bounded by its heaviest image until then) and 4 beyond.  Results do not depend on the choice. */
 int lsd_set_region_waves(lsd_ctx *ctx, int waves);
+/* Help across workgroups in the region stage: wavefronts of workgroups whose image is finished evaluate seeds of the images
+ * still running (up to `waves` helper wavefronts per image; default 24, 0: none, -1: back to the default).  It shortens ONE
+ * batch (its last images no longer run on a CU each with the rest of the GPU idle).  A caller that keeps several batches
+ * in flight -- one context and one stream per batch -- should switch it off: the next batch's workgroups fill the idle
+ * CUs, and helpers would hold them (bench.py does exactly that).  Results do not depend on the setting. */
+int lsd_set_region_help(lsd_ctx *ctx, int waves);
 /* Test hook: the region stage marks the pixels of the region it is growing with a fresh 32-bit id per grow; a wavefront that
  * uses up its 2^20 ids within one run clears its stamp array and starts over.  That takes more than a million grows by one
  * wavefront on one image; this lowers the budget (2 .. 0xFFFF0 grows) so that tests reach the path.  Results do not change. */

@@ -104,6 +104,7 @@ def load_library(path=None):
     L.lsd_set_stop_after.restype = i; L.lsd_set_stop_after.argtypes = [vp, i]
     L.lsd_set_trace.restype = i; L.lsd_set_trace.argtypes = [vp, i]
     L.lsd_set_region_waves.restype = i; L.lsd_set_region_waves.argtypes = [vp, i]
+    L.lsd_set_region_help.restype = i; L.lsd_set_region_help.argtypes = [vp, i]
     L.lsd_debug_set_stamp_budget.restype = i; L.lsd_debug_set_stamp_budget.argtypes = [vp, C.c_uint]
     L.lsd_set_host_max_lines.restype = i; L.lsd_set_host_max_lines.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
@@ -132,7 +133,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_debug_set_stamp_budget", "lsd_set_host_max_lines",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
@@ -316,6 +317,11 @@ class Context:
     def set_region_waves(self, waves):
         """0: automatic, 4 / 8: force the region-stage variant (results are identical)."""
         self._chk(self.L.lsd_set_region_waves(self.h, waves))
+
+    def set_region_help(self, waves):
+        """Helper wavefronts per image of the region stage's help across workgroups (lsd_set_region_help): 0 switches it off (the
+        setting for several batches in flight on several contexts), -1 restores the default.  Results are identical."""
+        self._chk(self.L.lsd_set_region_help(self.h, waves))
 
     def fetch(self, image, what, shape_wh):
         """Returns the intermediate `what` (DBG_*) of image `image` of the last run as a numpy array."""

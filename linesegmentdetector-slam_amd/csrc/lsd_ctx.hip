@@ -375,6 +375,12 @@ int lsd_set_region_waves(lsd_ctx* c, int waves) {
     return LSD_OK;
 }
 
+int lsd_set_region_help(lsd_ctx* c, int waves) {
+    if (!c || waves < -1 || waves > 4096) return LSD_ERR_INVALID;
+    c->tun_help = waves;
+    return LSD_OK;
+}
+
 int lsd_debug_set_stamp_budget(lsd_ctx* c, unsigned grows) {
     if (!c || grows < 2u || grows > 0xFFFF0u) return LSD_ERR_INVALID;
     c->id_budget = grows;

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Developer probe: throughput of the bench batch when consecutive steps overlap (D contexts on D streams, step i on slot i % D):
+the tail of one step's region stage -- a few images on a CU each -- runs next to the head of the next one's.
+   tools/pipeline_probe.py [depth ...]"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, torch
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+maps = bench.load_maps(); n, size = 512, 2048
+d = torch.from_numpy(bench.make_batch(maps, n, size)).cuda()
+for depth in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
+    ctxs = [lsd.Context(0) for _ in range(depth)]
+    for c_ in ctxs: c_.set_region_waves(int(os.environ.get("WAVES", "0")))
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    outs = [(torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros((n, size, size), dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    def step(i):
+        j = i % depth
+        l, c, im = outs[j]
+        ctxs[j].enqueue_device(d.data_ptr(), n, size, size, l.data_ptr(), 1024, c.data_ptr(), d_line_ims=im.data_ptr(), stream=streams[j].cuda_stream)
+    for i in range(depth): step(i)
+    torch.cuda.synchronize()
+    K = 12
+    t0 = time.perf_counter()
+    for i in range(K): step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    ok = all(int(o[1].sum()) == 138815 for o in outs)
+    tm = ctxs[0].timings()
+    print("depth %d: %.1f ms per step = %.1f Gpix/s; lines ok %s; last launch on slot 0: gauss %.2f gradient %.2f sort %.2f region %.1f" % (depth, dt * 1e3, n * size * size / dt / 1e9, ok, tm["gauss"], tm["gradient"], tm["sort"], tm["region"]), flush=True)
+    del ctxs, outs
+    torch.cuda.empty_cache()
