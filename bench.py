@@ -152,8 +152,8 @@ def cpu_baseline(size, first, sample=24, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)

@@ -2346,7 +2346,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 
     // ---- ... then help elsewhere: every wavefront on its own (see "Help from other workgroups" above) ----
     if (lane < NS) slot_k_l = -1;
-    int hx = -1, hj = 0, hidle = 0;                         // image this wave helps (-1: none), request it is answering, looks without work
+    int hx = -1, hj = 0, hidle = 0, hscan = 0;              // image this wave helps (-1: none), request it is answering, looks without work / for an image
     uint32_t* hrec = nullptr;                               // that image's record of the help protocol
     const uint32_t* cur_seedpos = seedpos;
     while (true) {
@@ -2380,6 +2380,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             best = (uint32_t)uni((int)best);
             if (!best) {
                 if (early) { if (lane == 0) atomicSub(&xhdr[3], 1u); break; }
+                if (++hscan > b.tun_linger) break;         // nobody has asked for a while: give the CU back (another launch may be waiting for it)
                 for (int t = 0; t < 8; t++) __builtin_amdgcn_s_sleep(127);
                 continue;
             }
@@ -2391,7 +2392,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
                 else ok = 1;
             }
             if (!__builtin_amdgcn_readfirstlane(ok)) continue;
-            hx = (int)im; hrec = rc; hidle = 0;
+            hx = (int)im; hrec = rc; hidle = 0; hscan = 0;
             cur_seedpos = b.seedpos + (size_t)im * npx;
             c.mag = b.mag + (size_t)im * npx; c.deg = b.deg + (size_t)im * npx; c.pw = b.pw + (size_t)im * npx;
             c.epochmap = b.epochmap + (size_t)im * npx; c.sc = b.sc + (size_t)im * npx;

@@ -440,6 +440,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         { const char* e = getenv("LSD_REGION_UP"); b.tun_up = e ? atoi(e) : 32; e = getenv("LSD_REGION_DOWN"); b.tun_down = e ? atoi(e) : 96; }
         { const char* e = getenv("LSD_REGION_REQUEUE"); b.tun_requeue = e ? atoi(e) : 1; }
         { const char* e = getenv("LSD_REGION_XPOLL"); b.tun_xpoll = e ? atoi(e) : 20000; }
+        { const char* e = getenv("LSD_REGION_LINGER"); b.tun_linger = e ? atoi(e) : 40; }
         { const char* e = getenv("LSD_REGION_STOP"); b.tun_stop = e ? atoi(e) : 0; }
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
     }

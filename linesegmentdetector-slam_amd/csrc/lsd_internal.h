@@ -80,6 +80,7 @@ struct Buffers {
     int tun_up, tun_down;  // steps of the adaptive look-ahead (seeds): up when a wave finds nothing to do, down on a redo / discard
     int tun_requeue;       // results invalidated by a line are queued for another evaluation when the line is accepted (1) or found at the cursor (0)
     int tun_xpoll;         // shader clocks between two looks of a wave at the help protocol
+    int tun_linger;        // looks (~27 us each) a helper wavefront takes for an image that asks before it gives its CU back
     int tun_stop;          // experiments: the seed loop ends after this many potential seeds (0: all)
     double* pend;          // n x NW x NS x 24 : finished results that mark usedMap, waiting for their turn to commit
     double* recs;          // n x max_lines x 12 (structRec before rescale)

@@ -20,13 +20,21 @@ for depth in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
         ctxs[j].enqueue_device(d.data_ptr(), n, size, size, l.data_ptr(), 1024, c.data_ptr(), d_line_ims=im.data_ptr(), stream=streams[j].cuda_stream)
     for i in range(depth): step(i)
     torch.cuda.synchronize()
-    K = 12
+    K = int(os.environ.get("K", "12"))
     t0 = time.perf_counter()
     for i in range(K): step(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
     ok = all(int(o[1].sum()) == 138815 for o in outs)
     tm = ctxs[0].timings()
+    wh = lsd.scaled_size(size, size)
+    for j in range(min(depth, 2)):
+        st = [ctxs[j].fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
+        cyc = np.array([x["cycles_total"] for x in st]) / 1e6
+        t0s = np.array([x["wd_pend"] for x in st], float) / 1e5; t1s = np.array([x["wd_wave"] for x in st], float) / 1e5
+        b0 = t0s - t0s.min(); e0 = t1s - t0s.min()
+        print("   slot %d last launch: Mcycles per image mean %.1f max %.0f | starts (ms after the first): p10 %.1f median %.1f p90 %.1f max %.1f | ends: median %.1f max %.1f" % (
+            j, cyc.mean(), cyc.max(), *np.percentile(b0, [10, 50, 90]), b0.max(), np.median(e0), e0.max()))
     print("depth %d: %.1f ms per step = %.1f Gpix/s; lines ok %s; last launch on slot 0: gauss %.2f gradient %.2f sort %.2f region %.1f" % (depth, dt * 1e3, n * size * size / dt / 1e9, ok, tm["gauss"], tm["gradient"], tm["sort"], tm["region"]), flush=True)
     del ctxs, outs
     torch.cuda.empty_cache()
