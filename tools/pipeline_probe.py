@@ -33,6 +33,8 @@ for depth in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
         cyc = np.array([x["cycles_total"] for x in st]) / 1e6
         t0s = np.array([x["wd_pend"] for x in st], float) / 1e5; t1s = np.array([x["wd_wave"] for x in st], float) / 1e5
         b0 = t0s - t0s.min(); e0 = t1s - t0s.min()
+        clk = np.array([x["cycles_total"] for x in st]) / np.maximum((t1s - t0s) * 1e-3 * 1e9 / 1e3, 1)   # cycles per ns -> GHz
+        print("   slot %d shader clock while the images ran: median %.2f GHz (p10 %.2f, p90 %.2f)" % (j, np.median(clk), *np.percentile(clk, [10, 90])))
         print("   slot %d last launch: Mcycles per image mean %.1f max %.0f | starts (ms after the first): p10 %.1f median %.1f p90 %.1f max %.1f | ends: median %.1f max %.1f" % (
             j, cyc.mean(), cyc.max(), *np.percentile(b0, [10, 50, 90]), b0.max(), np.median(e0), e0.max()))
     print("depth %d: %.1f ms per step = %.1f Gpix/s; lines ok %s; last launch on slot 0: gauss %.2f gradient %.2f sort %.2f region %.1f" % (depth, dt * 1e3, n * size * size / dt / 1e9, ok, tm["gauss"], tm["gradient"], tm["sort"], tm["region"]), flush=True)
