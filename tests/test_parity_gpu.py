@@ -787,6 +787,48 @@ def test_help_across_workgroups_changes_nothing(waves, maps, lsdmod, oracle):
     assert res["24"][3] > 20 and res["24"][4] > 20, res["24"][3:]      # (hundreds on an idle device)
 
 
+def test_batches_in_flight_on_several_contexts(maps, lsdmod, ctx):
+    """Throughput mode (bench.py --pipeline): three batches in flight, one context and one stream each,
+    help across workgroups off, so that the workgroups of one batch's region stage fill the CUs the other's finished images
+    leave idle.  Every batch's counts, line records and lineIm equal those of the same batch run alone."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, size = 96, 1024
+    hosts = [bench.make_batch(maps, n, size, first) for first in (0, 96, 192)]
+    def run(c, d, outs, stream):
+        c.enqueue_device(d.data_ptr(), n, size, size, outs[0].data_ptr(), 1024, outs[1].data_ptr(), d_line_ims=outs[2].data_ptr(), stream=stream)
+    mk = lambda: (torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+                  torch.zeros((n, size, size), dtype=torch.uint8, device="cuda"))
+    devs = [torch.from_numpy(h).cuda() for h in hosts]
+    alone = []
+    for d in devs:
+        o = mk()
+        run(ctx, d, o, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        alone.append([t.cpu().numpy().tobytes() for t in o])
+    ctxs = [lsdmod.Context(0) for _ in devs]
+    streams = [torch.cuda.Stream() for _ in devs]
+    outs = [mk() for _ in devs]
+    try:
+        for c in ctxs:
+            c.set_region_help(0)
+            c.reserve(n, size, size)
+        for rep in range(3):                               # (the launches of the three streams interleave differently every time)
+            for o in outs:
+                for t in o: t.zero_()
+            torch.cuda.synchronize()
+            for c, d, o, st in zip(ctxs, devs, outs, streams):
+                run(c, d, o, st.cuda_stream)
+            torch.cuda.synchronize()
+            for o, ref in zip(outs, alone):
+                assert [t.cpu().numpy().tobytes() for t in o] == ref
+    finally:
+        for c in ctxs: c.close()
+    with pytest.raises(lsdmod.LsdError):
+        ctx.set_region_help(-2)
+
+
 def test_region_stage_variants_agree(maps, lsdmod, ctx, oracle):
     """The region stage exists with 4 and with 8 wavefronts per image (chosen by batch size): same lines, same usedMap."""
     crop = lambda a: np.ascontiguousarray(a[:600, :1600])
