@@ -152,8 +152,8 @@ def cpu_baseline(size, first, sample=24, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)
@@ -161,8 +161,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, map1 targets, single-image latency, copy ceiling): what the profiling passes use")
     ap.add_argument("--no-lineim", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
-    ap.add_argument("--pipeline", type=int, default=3, help="steps in flight: step i runs on context / stream i %% depth, so that the tail of one step's region stage "
+    ap.add_argument("--pipeline", type=int, default=4, help="steps in flight: step i runs on context / stream i %% depth, so that the tail of one step's region stage "
                     "(a few images on a CU each) overlaps the head of the next one's; 1 = one step at a time")
+    ap.add_argument("--waves", type=int, default=-1, choices=(-1, 0, 4, 8), help="wavefronts per image of the region stage in the timed region: 0 = the library's choice "
+                    "(8 for this batch size: lowest latency of one batch), 4 = two images per CU (highest throughput per CU); -1 = 4 with several steps in flight, else 0")
     a = ap.parse_args()
 
     import torch
@@ -200,6 +202,7 @@ def main():
     # resident input.  With several steps in flight the help across workgroups is off: the next step's workgroups take the
     # CUs a step's last images leave idle, helpers would hold them (include/lsd_hip.h, lsd_set_region_help).
     depth = max(1, a.pipeline)
+    waves = a.waves if a.waves >= 0 else (4 if depth > 1 else 0)
     ctxs = [ctx] + [lsd.Context(local) for _ in range(depth - 1)]
     outs = [(torch.zeros((n, a.max_lines, 10), dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
              None if a.no_lineim else torch.zeros((n, size, size), dtype=torch.uint8, device=dev)) for _ in range(depth)]
@@ -210,6 +213,7 @@ def main():
         c_.reserve(n, size, size)
         if depth > 1:
             c_.set_region_help(0)
+        c_.set_region_waves(waves)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
     cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)
@@ -249,6 +253,7 @@ def main():
     un_steps, un_dt = a.steps, dt
     if depth > 1:
         ctx.set_region_help(-1)
+        ctx.set_region_waves(0)
         un_steps = min(a.steps, 5)
         depth_saved, depth = depth, 1
         step(0, False); step(0, False)
@@ -308,7 +313,7 @@ def main():
                        "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU",
                        "rccl_gather_in_step": bool(use_dist),
-                       "steps_in_flight": depth},
+                       "steps_in_flight": depth, "region_waves_per_image": waves if waves else 8},
             # the timed region keeps `steps_in_flight` steps in flight (one context, stream and set of output buffers each);
             # `one_step_at_a_time` is the same step run alone, measured right after it -- the source of every per-kernel figure below
             "one_step_at_a_time": {"steps": un_steps, "ms_per_step": un_step_s * 1e3, "value": mpix / un_step_s, "unit": "Mpix/s",
