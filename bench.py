@@ -165,6 +165,7 @@ def main():
                     "(a few images on a CU each) overlaps the head of the next one's; 1 = one step at a time")
     ap.add_argument("--waves", type=int, default=-1, choices=(-1, 0, 4, 8), help="wavefronts per image of the region stage in the timed region: 0 = the library's choice "
                     "(8 for this batch size: lowest latency of one batch), 4 = two images per CU (highest throughput per CU); -1 = 4 with several steps in flight, else 0")
+    ap.add_argument("--help-waves", type=int, default=0, help="helper wavefronts per image (lsd_set_region_help) while several steps are in flight (experiments; 0 = off)")
     a = ap.parse_args()
 
     import torch
@@ -212,7 +213,7 @@ def main():
     for c_ in ctxs:
         c_.reserve(n, size, size)
         if depth > 1:
-            c_.set_region_help(0)
+            c_.set_region_help(a.help_waves)
         c_.set_region_waves(waves)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}

@@ -22,21 +22,28 @@ for depth in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
     torch.cuda.synchronize()
     K = int(os.environ.get("K", "12"))
     t0 = time.perf_counter()
-    for i in range(K): step(i)
+    enq = []
+    for i in range(K):
+        te = time.perf_counter(); step(i); enq.append((time.perf_counter() - te) * 1e3)
+    t_enq = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
+    if os.environ.get("ENQ"): print("   host: all %d enqueues took %.1f ms; per call: %s" % (K, t_enq, " ".join("%.0f" % x for x in enq)))
     dt = (time.perf_counter() - t0) / K
     ok = all(int(o[1].sum()) == 138815 for o in outs)
     tm = ctxs[0].timings()
     wh = lsd.scaled_size(size, size)
-    for j in range(min(depth, 2)):
-        st = [ctxs[j].fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
-        cyc = np.array([x["cycles_total"] for x in st]) / 1e6
-        t0s = np.array([x["wd_pend"] for x in st], float) / 1e5; t1s = np.array([x["wd_wave"] for x in st], float) / 1e5
-        b0 = t0s - t0s.min(); e0 = t1s - t0s.min()
-        clk = np.array([x["cycles_total"] for x in st]) / np.maximum((t1s - t0s) * 1e-3 * 1e9 / 1e3, 1)   # cycles per ns -> GHz
-        print("   slot %d shader clock while the images ran: median %.2f GHz (p10 %.2f, p90 %.2f)" % (j, np.median(clk), *np.percentile(clk, [10, 90])))
-        print("   slot %d last launch: Mcycles per image mean %.1f max %.0f | starts (ms after the first): p10 %.1f median %.1f p90 %.1f max %.1f | ends: median %.1f max %.1f" % (
-            j, cyc.mean(), cyc.max(), *np.percentile(b0, [10, 50, 90]), b0.max(), np.median(e0), e0.max()))
+    if os.environ.get("TIMELINE"):
+        # the last launch of every slot (the final `depth` steps: the first of them started in the steady state)
+        rows = []
+        for j in range(depth):
+            st = [ctxs[j].fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
+            t0s = np.array([x["wd_pend"] for x in st], float) / 1e5; t1s = np.array([x["wd_wave"] for x in st], float) / 1e5
+            cyc = np.array([x["cycles_total"] for x in st]) / 1e6
+            rows.append((t0s.min(), j, t0s, t1s, cyc))
+        base = min(r[0] for r in rows)
+        for t0min, j, t0s, t1s, cyc in sorted(rows):
+            print("   slot %d: first start %.1f ms, starts p50 %.1f p90 %.1f last %.1f | ends p50 %.1f p90 %.1f last %.1f | Mcycles mean %.0f max %.0f" % (
+                j, t0min - base, *(np.percentile(t0s, [50, 90]) - base), t0s.max() - base, *(np.percentile(t1s, [50, 90]) - base), t1s.max() - base, cyc.mean(), cyc.max()))
     print("depth %d: %.1f ms per step = %.1f Gpix/s; lines ok %s; last launch on slot 0: gauss %.2f gradient %.2f sort %.2f region %.1f" % (depth, dt * 1e3, n * size * size / dt / 1e9, ok, tm["gauss"], tm["gradient"], tm["sort"], tm["region"]), flush=True)
     del ctxs, outs
     torch.cuda.empty_cache()
