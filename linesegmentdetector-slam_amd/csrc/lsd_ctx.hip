@@ -23,6 +23,8 @@ struct lsd_ctx {
     uint32_t id_budget = 0xFFFF0u;     // curMap stamp ids a wave may use per run before it clears its stamps (lsd_debug_set_stamp_budget)
     int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: default), see k_region.hip
     int tun_help = -1;                                             // helper wavefronts per image (-1: default, 0: none)
+    // developer experiments (environment variables read once, when the context is created; DESIGN_NOTES.md says what each was for)
+    int tun_early = 0, tun_wb = 10, tun_up = 32, tun_down = 96, tun_requeue = 1, tun_xpoll = 20000, tun_linger = 40, tun_stop = 0;
     uint32_t* xq = nullptr;
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     bool prefer4 = false;              // the 8-wave workspace did not fit this device's memory once: batches run on 4 waves per image
@@ -338,6 +340,14 @@ int lsd_create(lsd_ctx** out, int device) {
         if ((e = getenv("LSD_REGION_FEED"))) c->tun_feed = atoi(e);
         if ((e = getenv("LSD_REGION_BIG"))) c->tun_big = atoi(e);
         if ((e = getenv("LSD_REGION_HELP"))) c->tun_help = atoi(e);
+        if ((e = getenv("LSD_REGION_EARLY"))) c->tun_early = atoi(e);          // helpers before every workgroup has its CU (measured: a loss)
+        if ((e = getenv("LSD_REGION_WB"))) c->tun_wb = atoi(e);                // idle share (%) below which an image asks for help
+        if ((e = getenv("LSD_REGION_UP"))) c->tun_up = atoi(e);                // steps of the adaptive look-ahead
+        if ((e = getenv("LSD_REGION_DOWN"))) c->tun_down = atoi(e);
+        if ((e = getenv("LSD_REGION_REQUEUE"))) c->tun_requeue = atoi(e);      // 0: invalidated results are found at the cursor only
+        if ((e = getenv("LSD_REGION_XPOLL"))) c->tun_xpoll = atoi(e);          // clocks between two looks of a wave at the help protocol
+        if ((e = getenv("LSD_REGION_LINGER"))) c->tun_linger = atoi(e);        // looks a helper takes for an image that asks before it gives its CU back
+        if ((e = getenv("LSD_REGION_STOP"))) c->tun_stop = atoi(e);            // the seed loop ends after this many seeds (probe experiment)
     }
     *out = c;
     return LSD_OK;
@@ -435,13 +445,8 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
         b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
-        { const char* e = getenv("LSD_REGION_EARLY"); b.tun_early = e ? atoi(e) : 0; }
-        { const char* e = getenv("LSD_REGION_WB"); b.tun_wb = e ? atoi(e) : 10; }
-        { const char* e = getenv("LSD_REGION_UP"); b.tun_up = e ? atoi(e) : 32; e = getenv("LSD_REGION_DOWN"); b.tun_down = e ? atoi(e) : 96; }
-        { const char* e = getenv("LSD_REGION_REQUEUE"); b.tun_requeue = e ? atoi(e) : 1; }
-        { const char* e = getenv("LSD_REGION_XPOLL"); b.tun_xpoll = e ? atoi(e) : 20000; }
-        { const char* e = getenv("LSD_REGION_LINGER"); b.tun_linger = e ? atoi(e) : 40; }
-        { const char* e = getenv("LSD_REGION_STOP"); b.tun_stop = e ? atoi(e) : 0; }
+        b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
+        b.tun_xpoll = c->tun_xpoll; b.tun_linger = c->tun_linger; b.tun_stop = c->tun_stop;
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
     }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
