@@ -24,7 +24,7 @@ struct lsd_ctx {
     int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: default), see k_region.hip
     int tun_help = -1;                                             // helper wavefronts per image (-1: default, 0: none)
     // developer experiments (environment variables read once, when the context is created; DESIGN_NOTES.md says what each was for)
-    int tun_early = 0, tun_wb = 10, tun_up = 32, tun_down = 96, tun_requeue = 1, tun_xpoll = 20000, tun_linger = 40, tun_stop = 0;
+    int tun_early = 0, tun_wb = 10, tun_up = 32, tun_down = 96, tun_requeue = 1, tun_xpoll = 20000, tun_linger = 1000000, tun_stop = 0;
     uint32_t* xq = nullptr;
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
     bool prefer4 = false;              // the 8-wave workspace did not fit this device's memory once: batches run on 4 waves per image
@@ -346,7 +346,8 @@ int lsd_create(lsd_ctx** out, int device) {
         if ((e = getenv("LSD_REGION_DOWN"))) c->tun_down = atoi(e);
         if ((e = getenv("LSD_REGION_REQUEUE"))) c->tun_requeue = atoi(e);      // 0: invalidated results are found at the cursor only
         if ((e = getenv("LSD_REGION_XPOLL"))) c->tun_xpoll = atoi(e);          // clocks between two looks of a wave at the help protocol
-        if ((e = getenv("LSD_REGION_LINGER"))) c->tun_linger = atoi(e);        // looks a helper takes for an image that asks before it gives its CU back
+        if ((e = getenv("LSD_REGION_LINGER"))) c->tun_linger = atoi(e);        // looks (~27 us each) a helper takes for an image that asks before it gives its CU back (default: it stays while images run;
+                                                                               //  with 40 the one heavy image of a 64-image shard got help in one launch out of three)
         if ((e = getenv("LSD_REGION_STOP"))) c->tun_stop = atoi(e);            // the seed loop ends after this many seeds (probe experiment)
     }
     *out = c;
