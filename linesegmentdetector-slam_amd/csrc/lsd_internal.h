@@ -17,7 +17,7 @@ constexpr int kPTable = 16;                     // host-tabulated log(p), log10(
 //   answers (seed + 1); [3R, 11R) the answers, 8 words each: result state, result slot, accept epoch of the snapshot, box (2),
 //   list sizes (R = kXReq).  After the n image records (kXHdr words): [0] workgroups started [1] images finished [2] length
 //   of the list of images that ask for help; the list (image + 1) follows.
-constexpr int kXStride = 512, kXReq = 32, kXHdr = 16;
+constexpr int kXStride = 768, kXReq = 64, kXHdr = 16;
 
 // Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
 // host libm so that they are the very numbers the reference computes (myLSD.cpp:132-133,148-149,207-209).
