@@ -787,6 +787,34 @@ def test_help_across_workgroups_changes_nothing(waves, maps, lsdmod, oracle):
     assert res["24"][3] > 20 and res["24"][4] > 20, res["24"][3:]      # (hundreds on an idle device)
 
 
+@pytest.mark.parametrize("env", [{"LSD_REGION_REQUEUE": "0"}, {"LSD_REGION_SOFT": "64", "LSD_REGION_CLAIM": "64"},
+                                 {"LSD_REGION_SOFT": "1900", "LSD_REGION_CLAIM": "1900", "LSD_REGION_BIG": "16"},
+                                 {"LSD_REGION_HELP": "64", "LSD_REGION_WB": "100", "LSD_REGION_XPOLL": "2000"}])
+def test_schedule_of_the_region_stage_changes_nothing(env, maps, lsdmod, ctx):
+    """How far the wavefronts work ahead of the commit cursor, whether invalidated results are re-queued when a line is accepted
+    or found at the cursor, who may ask for help and how often the help protocol is looked at: all of it is schedule.  A
+    48-image slice of the bench batch (1024 x 1024, heavy and light images mixed) gives the same bytes under each setting as
+    under the defaults (the settings are read when a context is created)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    batch = bench.make_batch(maps, 48, 1024, 140)
+    ref = ctx.run_batch(batch.copy())
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c = lsdmod.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None: del os.environ[k]
+            else: os.environ[k] = v
+    try:
+        for rep in range(2):
+            got = c.run_batch(batch.copy())
+            assert all(a.tobytes() == b.tobytes() for a, b in zip(got, ref))
+    finally:
+        c.close()
+
+
 def test_batches_in_flight_on_several_contexts(maps, lsdmod, ctx):
     """Throughput mode (bench.py --pipeline): three batches in flight, one context and one stream each,
     help across workgroups off, so that the workgroups of one batch's region stage fill the CUs the other's finished images
