@@ -400,6 +400,63 @@ def test_whole_bench_batch_matches_oracle(maps, lsdmod, ctx, oracle):
     torch.cuda.empty_cache()
 
 
+def test_timed_configuration_of_the_bench_matches_oracle(maps, lsdmod, oracle):
+    """The configuration bench.py's `value` is timed on, exactly: the 512 x 2048x2048 batch, FOUR contexts / streams / output sets
+    in flight (bench.py --pipeline 4), the 4-wavefront region stage (lsd_set_region_waves 4), help across workgroups off
+    (lsd_set_region_help 0), no LSD_FLAG_WRITEBACK_MAP (the four steps share one resident input), three rounds of four steps.
+    Context 0 of the last round is compared with the oracle image by image (counts, line records, lineIm); every other
+    (round, context) result must equal it byte for byte -- counts, the valid line records and lineIm."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, size, depth, cap = 512, 2048, 4, 1024
+    host = bench.make_batch(maps, n, size)
+    d = torch.from_numpy(host).cuda()
+    ctxs = [lsdmod.Context(0) for _ in range(depth)]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    outs = [(torch.zeros((n, cap, 10), dtype=torch.int64, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+             torch.zeros((n, size, size), dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    keep = None
+    try:
+        for c in ctxs:
+            c.reserve(n, size, size)
+            c.set_region_help(0)
+            c.set_region_waves(4)
+        for rnd in range(3):
+            for o in outs:
+                for t in o: t.fill_(7)                     # (stale results of the round before cannot pass for new ones)
+            torch.cuda.synchronize()
+            for c, o, st in zip(ctxs, outs, streams):      # the four steps are enqueued back to back, as bench.py's timed loop does
+                c.enqueue_device(d.data_ptr(), n, size, size, o[0].data_ptr(), cap, o[1].data_ptr(), d_line_ims=o[2].data_ptr(), stream=st.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(d.cpu(), torch.from_numpy(host))                      # no write-back: the shared input is untouched
+            cnt0 = outs[0][1]
+            assert int(cnt0.min()) >= 0 and int(cnt0.max()) <= cap
+            valid = (torch.arange(cap, device="cuda")[None, :] < cnt0[:, None])[:, :, None]   # records below an image's count
+            for j in range(1, depth):
+                assert torch.equal(outs[j][1], cnt0), (rnd, j)
+                assert torch.equal(outs[j][0] * valid, outs[0][0] * valid), (rnd, j)
+                assert torch.equal(outs[j][2], outs[0][2]), (rnd, j)
+            if keep is None:
+                keep = [t.clone() for t in outs[0]]
+            else:
+                assert torch.equal(keep[1], cnt0) and torch.equal(keep[0] * valid, outs[0][0] * valid) and torch.equal(keep[2], outs[0][2]), rnd
+        cnt = outs[0][1].cpu().numpy()
+        rec = outs[0][0].cpu().numpy().view(np.uint8).reshape(n, cap, 80)
+        total = 0
+        for i in range(n):
+            ref = oracle.lsd(host[i].copy())
+            assert cnt[i] == len(ref["lines"]), i
+            assert np.array_equal(outs[0][2][i].cpu().numpy(), ref["lineIm"]), i
+            assert_lines_close(rec[i, :cnt[i]].copy().view(lsdmod.LINE_DTYPE).reshape(-1), ref["lines"])
+            total += int(cnt[i])
+        assert total == 138815                                                 # lines_per_step of the bench line
+    finally:
+        for c in ctxs: c.close()
+        del d, outs, keep
+        torch.cuda.empty_cache()
+
+
 def test_bench_strong_scaling_split(maps, lsdmod, ctx):
     """bench.py --scaling strong (BASELINE configs[4]: the SAME batch split over the ranks by dist.shard_range) with world size 1:
     the JSON line carries the whole batch's answer."""
