@@ -33,7 +33,8 @@ enum {
     LSD_ERR_HIP = 3,            /* a HIP runtime call failed; see lsd_last_error() */
     LSD_ERR_UNSUPPORTED = 4,    /* parameter outside the implemented range (e.g. pseBin > 1024) */
     LSD_ERR_CAPACITY = 5,       /* more lines than max_lines in at least one image */
-    LSD_ERR_NOMEM = 6
+    LSD_ERR_NOMEM = 6,
+    LSD_ERR_INTERNAL = 7        /* the region stage's watchdog gave an image up (a defect detector; lsd_last_error() names the image) */
 };
 
 /* The five LSD knobs of myLineSegmentDetector (LSD/myLSD.h:132); defaults LSD/baseFunc.h:64-68. */
@@ -92,8 +93,11 @@ int lsd_set_host_max_lines(lsd_ctx *ctx, int max_lines);
  *   d_maps     n x rows x cols uint8, read-only unless LSD_FLAG_WRITEBACK_MAP is set
  *   d_line_ims n x rows x cols uint8 or NULL
  *   d_lines    n x max_lines lsd_line (image i's lines start at d_lines + i*max_lines)
- *   d_counts   n int32 line counts (a count > max_lines means that image overflowed: LSD_ERR_CAPACITY
- *              is reported by lsd_batch_status, the first max_lines lines are valid)
+ *   d_counts   n int32 line counts.  A count > max_lines means that image overflowed (its first max_lines lines are valid; the
+ *              host entry points report LSD_ERR_CAPACITY).  A count of -1 means the region stage's watchdog gave the image up
+ *              (no wavefront of its workgroup found anything to do for seconds: a defect of the commit protocol, never seen
+ *              on a released build): the image has no valid lines, its lineIm is blank, the other images are unaffected;
+ *              the host entry points report LSD_ERR_INTERNAL and treat the image as having no lines.
  *   stream     hipStream_t on which to enqueue (NULL = the default stream, as everywhere in HIP).  Asynchronous:
  *              returns after enqueueing; workspace is (re)allocated before the first launch only
  *              when (n, cols, rows) grew. */
@@ -143,11 +147,13 @@ int lsd_enqueue_scan_to_map_match_device(lsd_ctx *ctx, const double *d_map_cache
                                          double max_esti_dist, lsd_match_score *d_out, void *stream);
 
 /* --- scan-line extraction batch (SURVEY 8f "next" #4) ------------------------------------------- */
-/* Replaces myrdp::FeatureScan (LSD/myRDP.cpp:9-185; RegionSegmentation :304-389, SplitMerge / SplitMergeAssistant :187-302,
- * getThresholdDeltaDist :391-412; caller LSD/main_on_windows.cpp:127) for a BATCH of lidar scans: n_scans scans at a pitch of
+/* Replaces myrdp::FeatureScan (LSD/myRDP.cpp:9-185; RegionSegmentation :274-345, SplitMerge / SplitMergeAssistant :187-272,
+ * getThresholdDeltaDist :347-368; caller LSD/main_on_windows.cpp:127) for a BATCH of lidar scans: n_scans scans at a pitch of
  * `stride` readings, scan i holding lens[i] <= stride finite readings (range, angle) -- what the caller's read loop leaves
  * after dropping the infinite ranges (:115-121).  Per scan i:
- *   lines_out[i * 360 .. ]   the line records (structLinesInfo) in the reference's order, n_lines[i] of them (<= 360, :39)
+ *   lines_out[i * 360 .. ]   the line records (structLinesInfo) in the reference's order; n_lines[i] is their number, of which the
+ *                            first 360 are stored (the reference's malloc, :39, which it would overrun: the host entry point returns
+ *                            LSD_ERR_CAPACITY when a scan has more, the stored records are valid)
  *   pts_out[i * pts_cap .. ] scanImPoint: the pixels of the lines' rasters (x, y, 0) in the reference's order; n_pts[i] is
  *                            their number, of which the first pts_cap are stored
  *   lidar_pos[2 i .. ]       structLidarPointRec lidarPos (x, y), :33-36;  im_size[2 i ..] = (cols, rows) of FS.lineIm, :31

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsdhip.so")
 
 # ---- constants mirrored from include/lsd_hip.h -------------------------------------------------
-LSD_OK, LSD_ERR_INVALID, LSD_ERR_NO_DEVICE, LSD_ERR_HIP, LSD_ERR_UNSUPPORTED, LSD_ERR_CAPACITY, LSD_ERR_NOMEM = range(7)
+LSD_OK, LSD_ERR_INVALID, LSD_ERR_NO_DEVICE, LSD_ERR_HIP, LSD_ERR_UNSUPPORTED, LSD_ERR_CAPACITY, LSD_ERR_NOMEM, LSD_ERR_INTERNAL = range(8)
 LSD_FLAG_WRITEBACK_MAP = 1
 STAGE_ALL, STAGE_GAUSS, STAGE_GRAD, STAGE_SORT, STAGE_REGION = range(5)
 (DBG_GAUSS, DBG_MAG, DBG_DEG, DBG_STATE, DBG_ORDER, DBG_ORDER_VAL, DBG_NB, DBG_MAXGRAD, DBG_RECS, DBG_SEEDS,
@@ -262,6 +262,7 @@ class Context:
         lines = np.zeros((n, 360), LINE_DTYPE); pts = np.zeros((n, pts_cap, 3), np.float64)
         nl = np.zeros(n, np.int32); npt = np.zeros(n, np.int32); lp = np.zeros((n, 2), np.float64); sz = np.zeros((n, 2), np.int32)
         mp = lsd_map_param(int(map_param[0]), int(map_param[1]), float(map_param[2]), float(map_param[3]), float(map_param[4]))
+        # (more than 360 line records in a scan -- the reference would overrun its array there -- raises LsdError(LSD_ERR_CAPACITY))
         self._chk(self.L.lsd_feature_scan_batch(self.h, sc.ctypes.data, ln.ctypes.data, n, stride, mp, int(region_point_limit), float(thre_line),
                                                 float(line_dist_thre_m), lines.ctypes.data, nl.ctypes.data, pts.ctypes.data, pts_cap,
                                                 npt.ctypes.data, lp.ctypes.data, sz.ctypes.data))

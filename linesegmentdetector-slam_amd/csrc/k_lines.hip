@@ -66,33 +66,40 @@ __global__ __launch_bounds__(256) void k_lines(const double* __restrict__ recs_s
 }
 
 // Host entry points: the per-image line arrays (max_lines apart) compacted into one flat array + prefix offsets, so that
-// the host fetches exactly the lines there are in one copy.  offsets[n + 2]: offsets[n] = total, offsets[n + 1] = number of
-// images with more than max_lines lines (they are clamped; the host reports LSD_ERR_CAPACITY).  Two launches: a one-workgroup
-// scan of the counts, then one workgroup per image moves its records (size_t indices: n * max_lines * 10 words may pass 2^31).
+// the host fetches exactly the lines there are in one copy.  offsets[n + 3]: offsets[n] = total, offsets[n + 1] = number of
+// images with more than max_lines lines (they are clamped; the host reports LSD_ERR_CAPACITY), offsets[n + 2] = 1 + index of
+// the first image the region stage gave up (counts == -1, its watchdog; 0: none -- such an image contributes no lines and the
+// host reports LSD_ERR_INTERNAL).  Two launches: a one-workgroup scan of the counts, then one workgroup per image moves its
+// records (size_t indices: n * max_lines * 10 words may pass 2^31).
+__device__ __forceinline__ int kept_lines(int count, int max_lines) { return max(0, min(count, max_lines)); }
 __global__ __launch_bounds__(256) void k_scan_counts(const int32_t* __restrict__ counts, int max_lines, int n, int32_t* __restrict__ offsets) {
     __shared__ int s_part[256];
     __shared__ int s_over[256];
+    __shared__ int s_bad[256];
     const int t = threadIdx.x;
     const int per = (n + 255) / 256, lo = min(t * per, n), hi = min(lo + per, n);
-    int sum = 0, over = 0;
-    for (int i = lo; i < hi; i++) { sum += min(counts[i], max_lines); over += counts[i] > max_lines ? 1 : 0; }
-    s_part[t] = sum; s_over[t] = over;
+    int sum = 0, over = 0, bad = 0;
+    for (int i = lo; i < hi; i++) {
+        sum += kept_lines(counts[i], max_lines); over += counts[i] > max_lines ? 1 : 0;
+        if (counts[i] < 0 && !bad) bad = i + 1;
+    }
+    s_part[t] = sum; s_over[t] = over; s_bad[t] = bad;
     __syncthreads();
     if (t == 0) {
-        int run = 0, ov = 0;
-        for (int j = 0; j < 256; j++) { const int v = s_part[j]; s_part[j] = run; run += v; ov += s_over[j]; }
-        offsets[n] = run; offsets[n + 1] = ov;
+        int run = 0, ov = 0, bad = 0;
+        for (int j = 0; j < 256; j++) { const int v = s_part[j]; s_part[j] = run; run += v; ov += s_over[j]; if (!bad) bad = s_bad[j]; }
+        offsets[n] = run; offsets[n + 1] = ov; offsets[n + 2] = bad;
     }
     __syncthreads();
     int run = s_part[t];
-    for (int i = lo; i < hi; i++) { offsets[i] = run; run += min(counts[i], max_lines); }
+    for (int i = lo; i < hi; i++) { offsets[i] = run; run += kept_lines(counts[i], max_lines); }
 }
 __global__ __launch_bounds__(256) void k_compact_lines(const lsd_line* __restrict__ lines, const int32_t* __restrict__ counts,
                                                        int max_lines, const int32_t* __restrict__ offsets, lsd_line* __restrict__ flat) {
     const size_t i = blockIdx.x;
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(lines) + i * (size_t)max_lines * 10;
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(flat) + (size_t)offsets[i] * 10;
-    const size_t k = (size_t)min(counts[i], max_lines) * 10;
+    const size_t k = (size_t)kept_lines(counts[i], max_lines) * 10;
     for (size_t j = threadIdx.x; j < k; j += 256) dst[j] = src[j];
 }
 

@@ -1,7 +1,7 @@
 // k_rdp.hip -- myrdp::FeatureScan for a BATCH of lidar scans (gfx950): one wavefront per scan.
 //
-// Replaces LSD/myRDP.cpp:9-185 (FeatureScan) with its callees RegionSegmentation (:304-389), SplitMerge (:187-221),
-// SplitMergeAssistant (:223-302) and getThresholdDeltaDist (:391-412), SURVEY 8f #4.  The reference handles one scan of at most
+// Replaces LSD/myRDP.cpp:9-185 (FeatureScan) with its callees RegionSegmentation (:274-345), SplitMerge (:187-217),
+// SplitMergeAssistant (:219-272) and getThresholdDeltaDist (:347-368), SURVEY 8f #4.  The reference handles one scan of at most
 // 360 readings per frame on the host (LSD/main_on_windows.cpp:127); this is the batched form: N scans of len[i] readings each,
 // results at fixed strides.  Per scan:
 //   1. metric coordinates of the readings (lanes), the gaps between neighbours against the range-dependent threshold (lanes),
@@ -12,7 +12,7 @@
 //      line records (one lane per line; atand / cosd / sind are the correctly rounded ones of the LSD path), and the pixels of
 //      their rasters are listed in the reference's order (line by line; a prefix sum over the lines' pixel counts).
 // IEEE corner cases are kept as they are: a vertical chord has an infinite slope, its distances are NaN and nothing is split
-// (:245-262); (int) casts of non-finite values follow x86 (cvt_x86).  The reference's read one past its point array (:354-358)
+// (:245-257); (int) casts of non-finite values follow x86 (cvt_x86).  The reference's read one past its point array (:318-322)
 // is of a value it never uses and is not made.
 #include "lsd_internal.h"
 #include "devmath.h"
@@ -22,7 +22,7 @@ namespace lsdhip {
 constexpr int kRdpMaxLen = 1024;                    // readings per scan this kernel takes (the reference: 360)
 constexpr int kRdpMaxLines = 360;                   // line records per scan (the reference's malloc, :39)
 
-__device__ __forceinline__ double rdp_thre_delta(double val) {                      // getThresholdDeltaDist :391-412
+__device__ __forceinline__ double rdp_thre_delta(double val) {                      // getThresholdDeltaDist :347-368
     if (val <= 0.3) return 0.02;
     if (val <= 0.5) return 0.05;
     if (val <= 0.8) return 0.11;
@@ -60,18 +60,18 @@ __global__ __launch_bounds__(64) void k_rdp(const double* __restrict__ scans /* 
     for (int i = lane; i < len_lp; i += 64) {
         double s, c;
         sincos_g(sc[2 * i + 1] + 0.0, s, c);
-        px[i] = sc[2 * i] * c + 0.0;                                               // :310-311
+        px[i] = sc[2 * i] * c + 0.0;                                               // :286-287
         py[i] = sc[2 * i] * s + 0.0;
         split[i] = 0;
     }
     __syncthreads();
     for (int i = lane; i < len_lp; i += 64) {
-        const int nx = i == len_lp - 1 ? 0 : i + 1;                                // :327-334
+        const int nx = i == len_lp - 1 ? 0 : i + 1;                                // :299-306
         const double dX = px[i] - px[nx], dY = py[i] - py[nx];
-        brk[i] = sqrt(dX * dX + dY * dY) > rdp_thre_delta(sc[2 * i]) ? 1 : 0;      // :335-337
+        brk[i] = sqrt(dX * dX + dY * dY) > rdp_thre_delta(sc[2 * i]) ? 1 : 0;      // :307-309
     }
     __syncthreads();
-    if (lane == 0) {                                                               // RegionSegmentation's walk :326-366
+    if (lane == 0) {                                                               // RegionSegmentation's walk :297-330
         int cellNumber = 0, startNum = 0;
         for (int i = 0; i < len_lp; i++) {
             if (brk[i]) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void k_rdp(const double* __restrict__ scans /* 
     }
     __syncthreads();
     const int cells = s_cells;
-    // 2. SplitMerge :187-221 / SplitMergeAssistant :223-302
+    // 2. SplitMerge :187-217 / SplitMergeAssistant :219-272
     for (int cidx = 0; cidx < cells; cidx++) {
         int sp_top = 0;
         if (lane == 0) { stk[0] = cs[cidx]; stk[1] = ce[cidx]; }
@@ -95,9 +95,9 @@ __global__ __launch_bounds__(64) void k_rdp(const double* __restrict__ scans /* 
             sp_top--;
             const int sp = stk[2 * sp_top], ep = stk[2 * sp_top + 1];
             __syncthreads();
-            const int len = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;          // :228-243
+            const int len = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;          // :223-239
             if (len <= 2) continue;
-            const double k = (py[ep] - py[sp]) / (px[ep] - px[sp]);                // :249-250
+            const double k = (py[ep] - py[sp]) / (px[ep] - px[sp]);                // :245-246
             const double d = py[ep] - k * px[ep];
             const double den = sqrt(k * k + 1);
             double best = 0.0;                                                     // dist_max = 0: only a distance > 0 is taken (:257)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_rdp(const double* __restrict__ scans /* 
             int i_max = 0;                                                         // :252 (reading 0 when nothing was farther than 0)
             if (besto != 0x7fffffff) { i_max = sp + besto; if (i_max >= len_lp) i_max -= len_lp; }
             const double r = sc[2 * i_max];
-            const double threDist = r > 9 ? r * thre_line : thre_line;             // :263-267
+            const double threDist = r > 9 ? r * thre_line : thre_line;             // :259-263
             if (best > threDist) {
                 if (lane == 0) {
                     stk[2 * sp_top] = (short)sp; stk[2 * sp_top + 1] = (short)i_max;

@@ -63,7 +63,8 @@ namespace RVAR {
 #define LSD_REGION_WAIT_SLEEP 127      // x 64 clocks
 #endif
 #ifndef LSD_REGION_WATCHDOG
-#define LSD_REGION_WATCHDOG 600000     // sleeps of LSD_REGION_WAIT_SLEEP x 64 clocks (~3.4 us each) with the cursor standing still
+#define LSD_REGION_WATCHDOG 600000     // looks of one wave (a sleep of LSD_REGION_WAIT_SLEEP x 64 clocks, ~3.4 us, each) that found nothing to do
+                                       // while the cursor, as that wave saw it, never moved
 #endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
@@ -1367,6 +1368,12 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
     eo.precise = precise ? 1 : 0; eo.m_off = m_off; eo.mcnt = mcnt; eo.redo = redo ? 1 : 0;
 }
 
+// (developer build only: the seed loop can be cut short for the cost-probe experiments of DESIGN_NOTES.md; the product runs them all)
+#ifdef LSD_REGION_STATS
+__device__ __forceinline__ int seed_limit(int cnt, int stop) { return stop > 0 ? min(cnt, stop) : cnt; }
+#else
+__device__ __forceinline__ int seed_limit(int cnt, int) { return cnt; }
+#endif
 __device__ __forceinline__ int lds_ld(int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -1492,7 +1499,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = b.tun_stop > 0 ? min(cnt, b.tun_stop) : cnt; s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(cnt, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
         wg_fence();
     }
     __syncthreads();
@@ -1946,7 +1953,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
 
     int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done
     bool pend_spec = false;
-    int nwait = 0;                                          // consecutive looks that found nothing to do (watchdog)
+    int nwait = 0, wd_f = -1;                               // looks that found nothing to do since the cursor was last seen to move (watchdog)
     long long xlast = 0;                                    // when this wave last looked at the help protocol
     int xwant = 0;                                          // 1: look at the help protocol, 2: ... and the cursor stands on a seed given away
     while (true) {
@@ -2195,7 +2202,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             if (lds_ld(&s_next) >= nseeds && lds_ld(&s_commit) >= nseeds) break;   // everything is committed
             // Watchdog: the protocol has no state in which every wave waits; should one arise all the same (a defect), the image
             // is given up after seconds of nobody moving instead of hanging the device: counts[img] = -1, the state goes to stats.
-            if (lds_ld(&s_commit) != f) nwait = 0;
+            {   // (the cursor as this wave last saw it is kept across looks: movement during the sleep below, or by this wave's own
+                //  advance() at the top of the next look, counts)
+                const int fc = lds_ld(&s_commit);
+                if (fc != wd_f) { wd_f = fc; nwait = 0; }
+            }
             if (++nwait > LSD_REGION_WATCHDOG || lds_ld(&s_abort)) {
                 if (b.stats && lane == 0) {
                     long long* st = b.stats + img * kStatWords;
@@ -2244,6 +2255,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
             tw_small = false;
         }
         eval_seed(c.wave, pp, spec ? 1 : 0, slot);
+#ifdef LSD_REGION_INJECT_STALL
+        if (img & 1) continue;                             // test build (make wdtest): odd images never publish a full evaluation -> the watchdog has to end them
+#endif
         const EvalOut& eo = g_eo[wave];
         const bool skip = eo.skip != 0;
         const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;

@@ -296,6 +296,7 @@ const char* lsd_strerror(int st) {
         case LSD_ERR_UNSUPPORTED: return "parameter outside the implemented range";
         case LSD_ERR_CAPACITY: return "line capacity exceeded";
         case LSD_ERR_NOMEM: return "out of memory (host or device)";
+        case LSD_ERR_INTERNAL: return "the region stage gave an image up (its watchdog; see lsd_last_error)";
         default: return "unknown status";
     }
 }
@@ -333,22 +334,30 @@ int lsd_create(lsd_ctx** out, int device) {
         if (hipHostMalloc((void**)&c->pin[k], kPinBytes, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_NOMEM; }
     c->last_stream = c->stream;
-    {   // experiments: LSD_REGION_SOFT / _CLAIM / _FEED / _BIG override the schedule of the region stage
-        const char* e;
-        if ((e = getenv("LSD_REGION_SOFT"))) c->tun_soft = atoi(e);
-        if ((e = getenv("LSD_REGION_CLAIM"))) c->tun_claim = atoi(e);
-        if ((e = getenv("LSD_REGION_FEED"))) c->tun_feed = atoi(e);
-        if ((e = getenv("LSD_REGION_BIG"))) c->tun_big = atoi(e);
-        if ((e = getenv("LSD_REGION_HELP"))) c->tun_help = atoi(e);
-        if ((e = getenv("LSD_REGION_EARLY"))) c->tun_early = atoi(e);          // helpers before every workgroup has its CU (measured: a loss)
-        if ((e = getenv("LSD_REGION_WB"))) c->tun_wb = atoi(e);                // idle share (%) below which an image asks for help
-        if ((e = getenv("LSD_REGION_UP"))) c->tun_up = atoi(e);                // steps of the adaptive look-ahead
-        if ((e = getenv("LSD_REGION_DOWN"))) c->tun_down = atoi(e);
-        if ((e = getenv("LSD_REGION_REQUEUE"))) c->tun_requeue = atoi(e);      // 0: invalidated results are found at the cursor only
-        if ((e = getenv("LSD_REGION_XPOLL"))) c->tun_xpoll = atoi(e);          // clocks between two looks of a wave at the help protocol
-        if ((e = getenv("LSD_REGION_LINGER"))) c->tun_linger = atoi(e);        // looks (~27 us each) a helper takes for an image that asks before it gives its CU back (default: it stays while images run;
-                                                                               //  with 40 the one heavy image of a 64-image shard got help in one launch out of three)
-        if ((e = getenv("LSD_REGION_STOP"))) c->tun_stop = atoi(e);            // the seed loop ends after this many seeds (probe experiment)
+    {   // Schedule settings of the region stage from the environment (read once, here): none of them changes a result
+        // (tests/test_parity_gpu.py::test_schedule_of_the_region_stage_changes_nothing), each is clamped to the range the kernel
+        // assumes.  LSD_REGION_STOP (the seed loop cut short: it does change results) exists in the developer build only.
+        auto env_int = [](const char* name, int lo, int hi, int* out) {
+            const char* e = getenv(name);
+            if (!e || !*e) return;
+            char* end = nullptr;
+            const long v = strtol(e, &end, 10);
+            if (end == e) return;
+            *out = (int)(v < lo ? lo : v > hi ? hi : v);
+        };
+        env_int("LSD_REGION_SOFT", 0, 1 << 20, &c->tun_soft);        // look-ahead of the seed hand-out, shallow / deep end (seeds; 0: default)
+        env_int("LSD_REGION_CLAIM", 0, 1 << 20, &c->tun_claim);
+        env_int("LSD_REGION_FEED", 1, 8, &c->tun_feed);             // idle lane groups per refill
+        env_int("LSD_REGION_BIG", 0, 16, &c->tun_big);              // results a wave may have waiting for the cursor (0: default)
+        env_int("LSD_REGION_HELP", -1, 4096, &c->tun_help);         // helper wavefronts per image (as lsd_set_region_help)
+        env_int("LSD_REGION_EARLY", 0, 4096, &c->tun_early);        // helpers before every workgroup has its CU (measured: a loss)
+        env_int("LSD_REGION_WB", 0, 100, &c->tun_wb);               // idle share (%) below which an image asks for help
+        env_int("LSD_REGION_UP", 0, 1 << 16, &c->tun_up);           // steps of the adaptive look-ahead
+        env_int("LSD_REGION_DOWN", 0, 1 << 16, &c->tun_down);
+        env_int("LSD_REGION_REQUEUE", 0, 1, &c->tun_requeue);       // 0: invalidated results are found at the cursor only
+        env_int("LSD_REGION_XPOLL", 100, 1 << 30, &c->tun_xpoll);   // clocks between two looks of a wave at the help protocol
+        env_int("LSD_REGION_LINGER", 1, 1 << 30, &c->tun_linger);   // looks (~27 us each) a helper takes for an image that asks before it gives its CU back
+        env_int("LSD_REGION_STOP", 0, 1 << 30, &c->tun_stop);       // developer build: the seed loop ends after this many seeds (probe experiment)
     }
     *out = c;
     return LSD_OK;
@@ -557,7 +566,7 @@ static int ensure_host_staging(lsd_ctx* c, size_t n, size_t wh, int max_lines, b
         HIPCHK(c, re_alloc(&c->h_in, nn * ww));
         HIPCHK(c, re_alloc(&c->h_lineim, li ? nn * ww : 0));
         HIPCHK(c, re_alloc(&c->h_lines, nn * (size_t)ml)); HIPCHK(c, re_alloc(&c->h_flat, nn * (size_t)ml));
-        HIPCHK(c, re_alloc(&c->h_counts, nn)); HIPCHK(c, re_alloc(&c->h_offs, nn + 2));
+        HIPCHK(c, re_alloc(&c->h_counts, nn)); HIPCHK(c, re_alloc(&c->h_offs, nn + 3));
         c->hcap_n = nn; c->hcap_wh = ww; c->hcap_max_lines = ml; c->hcap_lineim = li;
     }
     return LSD_OK;
@@ -588,8 +597,8 @@ int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const ls
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev[1], 0));
     st = d2h_staged(c, maps, c->h_in, (size_t)n * wh, c->copy_stream);
     if (st != LSD_OK) return st;
-    std::vector<int32_t> offs((size_t)n + 2);                                                  // offsets[n + 1], then the overflow count
-    st = d2h_staged(c, offs.data(), c->h_offs, sizeof(int32_t) * (size_t)(n + 2), s);          // (waits for the pipeline)
+    std::vector<int32_t> offs((size_t)n + 3);                                                  // offsets[n + 1], the overflow count, 1 + first image given up
+    st = d2h_staged(c, offs.data(), c->h_offs, sizeof(int32_t) * (size_t)(n + 3), s);          // (waits for the pipeline)
     if (st != LSD_OK) return st;
     memcpy(offsets_out, offs.data(), sizeof(int32_t) * (size_t)(n + 1));
     const int total = offsets_out[n];
@@ -599,6 +608,12 @@ int lsd_run_batch(lsd_ctx* c, uint8_t* maps, int n, int cols, int rows, const ls
     if (st == LSD_OK && line_ims) st = d2h_staged(c, line_ims, c->h_lineim, (size_t)n * wh, s);
     if (st != LSD_OK) { free(out); return st; }
     *lines_out = out;
+    if (offs[(size_t)n + 2] > 0) {
+        // the region stage's watchdog gave an image up (a defect of its protocol, never seen on a released build): that image has
+        // no lines in the result, everything else is valid
+        c->err = "region stage gave up image " + std::to_string(offs[(size_t)n + 2] - 1) + " of the batch (watchdog; counts = -1)";
+        return LSD_ERR_INTERNAL;
+    }
     // more lines than host_max_lines in some image: the first host_max_lines of it are returned, and the status says so
     return offs[(size_t)n + 1] > 0 ? LSD_ERR_CAPACITY : LSD_OK;
 }
@@ -875,6 +890,8 @@ int lsd_feature_scan_batch(lsd_ctx* c, const lsd_polar* scans, const int* lens, 
     HIPCHK(c, hipMemcpyAsync(lidar_pos, d_lp, (size_t)n_scans * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(im_size, d_sz, (size_t)n_scans * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_scans; i++)
+        if (n_lines[i] > LSD_RDP_MAX_LINES) return LSD_ERR_CAPACITY;      // more chords than the 360 records per scan hold (the first 360 are valid)
     return LSD_OK;
 }
 

@@ -833,7 +833,7 @@ int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
 /* ------------------------------------------------------------------------------------ */
 /* myrdp::FeatureScan, LSD/myRDP.cpp (see lsd_oracle.h)                                  */
 /* ------------------------------------------------------------------------------------ */
-static double rdp_thre_delta(double val)                                  /* getThresholdDeltaDist :391-412 */
+static double rdp_thre_delta(double val)                                  /* getThresholdDeltaDist :347-368 */
 {
     if (val <= 0.3) return 0.02;
     if (val <= 0.5) return 0.05;
@@ -848,9 +848,9 @@ static double rdp_thre_delta(double val)                                  /* get
 }
 
 static void rdp_split(const orc_polar *sc, const double *px, const double *py, unsigned char *split, int len_lp, int sp, int ep,
-                      double threLine)                                    /* SplitMergeAssistant :223-302 */
+                      double threLine)                                    /* SplitMergeAssistant :219-272 */
 {
-    const int len = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;         /* :228-243 (the cluster may wrap around the scan) */
+    const int len = ep > sp ? ep - sp + 1 : len_lp + ep - sp + 1;         /* :223-239 (the cluster may wrap around the scan) */
     if (len <= 2) return;
     const double k = (py[ep] - py[sp]) / (px[ep] - px[sp]);               /* :249 */
     const double d = py[ep] - k * px[ep];
@@ -862,7 +862,7 @@ static void rdp_split(const orc_polar *sc, const double *px, const double *py, u
         const double dist = fabs(k * px[a] - py[a] + d) / sqrt(pow(k, 2) + 1);   /* :256 */
         if (dist > dist_max) { dist_max = dist; i_max = a; }
     }
-    const double threDist = sc[i_max].range > 9 ? sc[i_max].range * threLine : threLine;   /* :263-267 */
+    const double threDist = sc[i_max].range > 9 ? sc[i_max].range * threLine : threLine;   /* :259-263 */
     if (dist_max > threDist) {
         rdp_split(sc, px, py, split, len_lp, sp, i_max, threLine);
         rdp_split(sc, px, py, split, len_lp, i_max, ep, threLine);
@@ -882,7 +882,7 @@ int orc_feature_scan(orc_map_param mp, const orc_polar *scan, int len_lp, int re
     if (!px || !split || !cs || !axis) { free(px); free(split); free(cs); free(axis); return -3; }
     /* scanPose = {0, 0, 0} (:11) */
     for (int i = 0; i < len_lp; i++) { px[i] = scan[i].range * cos(scan[i].angle + 0.0) + 0.0; py[i] = scan[i].range * sin(scan[i].angle + 0.0) + 0.0; }
-    /* RegionSegmentation :304-389 */
+    /* RegionSegmentation :274-345 */
     int cellNumber = 0, startNum = 0;
     for (int i = 0; i < len_lp; i++) {
         const int nx = i == len_lp - 1 ? 0 : i + 1;
@@ -892,11 +892,11 @@ int orc_feature_scan(orc_map_param mp, const orc_polar *scan, int len_lp, int re
         if (deltaDist > thre) {
             cs[cellNumber] = startNum; ce[cellNumber] = i;                 /* :346-351 */
             if (abs(i - startNum) >= region_point_limit) cellNumber++;
-            startNum = i + 1;                                              /* :354-358 (the point itself is never used) */
+            startNum = i + 1;                                              /* :318-322 (the point itself is never used) */
         }
         if (deltaDist <= thre && i == len_lp - 1) cs[0] = startNum;        /* :361-365 the last cluster joins the first */
     }
-    /* SplitMerge :187-221 */
+    /* SplitMerge :187-217 */
     for (int c = 0; c < cellNumber; c++) rdp_split(scan, px, py, split, len_lp, cs[c], ce[c], thre_line);
     /* pixel coordinates and the image size :16-37 */
     double minX = INFINITY, minY = INFINITY, maxX = 0, maxY = 0;

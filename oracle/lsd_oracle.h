@@ -94,12 +94,12 @@ int orc_scan_to_map_match(const double *map_cache, int cols, int rows,
 }
 #endif
 
-/* ---- myrdp::FeatureScan (LSD/myRDP.cpp:9-185 with RegionSegmentation :304-389, SplitMerge :187-221, SplitMergeAssistant
- * :223-302, getThresholdDeltaDist :391-412): clusters one lidar scan, splits the clusters by Ramer-Douglas-Peucker and turns the
+/* ---- myrdp::FeatureScan (LSD/myRDP.cpp:9-185 with RegionSegmentation :274-345, SplitMerge :187-217, SplitMergeAssistant
+ * :219-272, getThresholdDeltaDist :347-368): clusters one lidar scan, splits the clusters by Ramer-Douglas-Peucker and turns the
  * chords of at least lineDistThreM metres into line records + the pixels of their raster.  SURVEY 8f #4.
  * PARITY: pinned only loosely -- data/ScanlinesInfo.txt holds the MATLAB prototype's 11 lines for one frame of data/Lidar.txt
  * (tests/test_oracle.py::test_feature_scan_against_the_matlab_golden); the reference cannot be built here.
- * The reference reads one element past its point array when the last reading closes a cluster (:354-358); the value is never
+ * The reference reads one element past its point array when the last reading closes a cluster (:318-322); the value is never
  * used, so the restatement does not read it.  A vertical chord makes its slope infinite (:245): IEEE arithmetic then gives NaN
  * distances and no split, which is restated as it is. */
 typedef struct { double range, angle; } orc_polar;                 /* structLidarPointPolar (myRDP.h:34-38) without its work flag */

@@ -1022,6 +1022,62 @@ def test_libm_tie_images_equal_the_correctly_rounded_restatement(name, kw, lsdmo
     assert len(lines) != len(oracle.lsd(img.copy(), **kw)["lines"])   # ... and differs from the glibc-built one (the caveat)
 
 
+def test_watchdog_failure_path_is_reported_not_fatal(maps, lsdmod, ctx):
+    """The region stage's watchdog gives an image up with counts = -1.  A test build of the library (make wdtest: odd images never
+    publish a full evaluation, the watchdog fires after ~10 ms) drives that path: the device entry point leaves -1 in the counts of
+    the odd images and the right answers in the even ones; the host entry point returns LSD_ERR_INTERNAL naming the first such
+    image, with offsets and lines that skip the given-up images instead of running out of bounds."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wd = os.path.join(root, "linesegmentdetector-slam_amd", "liblsdhip_wdtest.so")
+    if not os.path.exists(wd):
+        subprocess.run(["make", "-C", os.path.join(root, "linesegmentdetector-slam_amd", "csrc"), "-j4", "wdtest"], check=True, capture_output=True)
+    code = r"""
+import ctypes as C, importlib, json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+lsd = importlib.import_module("linesegmentdetector-slam_amd")
+maps = np.load(%r)
+img = np.ascontiguousarray(maps["aisle1"][:600, :800])
+batch = np.stack([img] * 5)
+c = lsd.Context(0)
+out = {}
+for waves in (4, 8):
+    c.set_region_waves(waves)
+    d = torch.from_numpy(batch).cuda()
+    L = torch.zeros((5, 256, 10), dtype=torch.int64, device="cuda"); cnt = torch.zeros(5, dtype=torch.int32, device="cuda")
+    ims = torch.zeros(batch.shape, dtype=torch.uint8, device="cuda")
+    c.enqueue_device(d.data_ptr(), 5, 800, 600, L.data_ptr(), 256, cnt.data_ptr(), d_line_ims=ims.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    res = dict(counts=cnt.cpu().tolist(), lit=[int((ims[i] == 255).sum()) for i in range(5)])
+    try:
+        c.run_batch(batch.copy())
+        res["status"] = 0
+    except lsd.LsdError as e:
+        res["status"] = e.status; res["msg"] = str(e)
+    # the raw call: offsets and lines skip the images that were given up
+    lp = C.c_void_p(); offs = (C.c_int * 6)(); p = lsd.make_params()
+    b2 = batch.copy()
+    res["st2"] = c.L.lsd_run_batch(c.h, b2.ctypes.data, 5, 800, 600, C.byref(p), None, C.byref(lp), offs)
+    res["offs"] = list(offs); c.L.lsd_free(lp)
+    out[waves] = res
+print(json.dumps(out))
+""" % (root, os.path.join(root, "tests", "golden", "maps.npz"))
+    env = dict(os.environ, LSD_HIP_LIB=wd)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    got = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    img = np.ascontiguousarray(maps["aisle1"][:600, :800])
+    lines, im = ctx.run(img.copy())
+    n, lit = len(lines), int((im == 255).sum())
+    assert n > 3
+    for waves in ("4", "8"):
+        r = got[waves]
+        assert r["counts"] == [n, -1, n, -1, n], r
+        assert r["lit"] == [lit, 0, lit, 0, lit], r
+        assert r["status"] == lsdmod.LSD_ERR_INTERNAL and "image 1" in r["msg"], r
+        assert r["st2"] == lsdmod.LSD_ERR_INTERNAL and r["offs"] == [0, n, n, 2 * n, 2 * n, 3 * n], r
+
+
 def test_out_of_memory_is_reported_not_fatal(lsdmod, ctx):
     """A batch whose workspace cannot fit in HBM: LSD_ERR_NOMEM, and the context keeps working."""
     with pytest.raises(lsdmod.LsdError) as e:
