@@ -78,6 +78,15 @@ def load_maps():
     return {k: z[k] for k in z.files}
 
 
+def keep_heap():
+    """glibc hands blocks above 128 KB straight to mmap and gives them back on free: every oracle call would map, page-fault and
+    unmap ~30 MB of work arrays (the reference's own malloc pattern).  Keeping the heap makes the calls after the first reuse it."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.mallopt(-3, 1 << 30)       # M_MMAP_THRESHOLD
+    libc.mallopt(-1, 1 << 30)       # M_TRIM_THRESHOLD
+
+
 # ---- CPU baseline (SURVEY 8d): the oracle = a single-threaded port of the reference path, on the GPU box's host cores ----
 def _cpu_worker(args):
     """One pinned single-thread oracle instance over its own slice of the batch (the reference has no intra-image threading)."""

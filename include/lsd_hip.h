@@ -110,6 +110,45 @@ int lsd_reserve(lsd_ctx *ctx, int n, int cols, int rows);
 /* Blocks until the stream used by the last enqueue is idle. */
 int lsd_synchronize(lsd_ctx *ctx);
 
+/* --- multi-GPU: image shards and the hand-off of the line lists (BASELINE configs[4]) ------------------------- */
+/* The reference runs one map on one host (LSD/main_on_windows.cpp:67-70, LSD/main_on_linux.cpp:130-132); a batch of independent
+ * maps is sharded over the GPUs of a node, one process (or thread) and one lsd_ctx per GPU, with no collective on the data path.
+ * The only exchange is the result hand-off below.
+ * lsd_shard_range: the contiguous shard [*lo, *hi) of n_items images that rank `rank` of `world` takes. */
+void lsd_shard_range(int n_items, int world, int rank, int *lo, int *hi);
+
+/* A communicator as this library sees it: who am I, how many are we, and ONE operation -- an all-gather of equally sized device
+ * buffers (d_recv holds world x bytes_per_rank, rank r's bytes at r * bytes_per_rank), enqueued on `stream`, 0 on success. */
+typedef struct lsd_comm {
+    int rank, world;
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+    void *user;
+} lsd_comm;
+/* Binds *out to an RCCL communicator (an ncclComm_t, passed as void*): rank / world from ncclCommUserRank / ncclCommCount,
+ * all_gather = ncclAllGather(..., ncclInt8, comm, stream) -- RCCL over xGMI between the GPUs of a node.  The RCCL symbols are taken
+ * from the calling process (the library the communicator belongs to), else from librccl.so.1; LSD_ERR_UNSUPPORTED without RCCL. */
+int lsd_comm_from_rccl(void *nccl_comm, lsd_comm *out);
+
+/* Sizes of the gathered arrays: *per_rank = images of the largest shard; *counts_words = world * (per_rank + 2) int32. */
+int lsd_gather_layout(int n_total, int world, int *per_rank, size_t *counts_words);
+
+/* Hands this rank's line lists to every rank.  d_lines / d_counts: the outputs of lsd_enqueue_batch_device for this rank's shard
+ * (n_local == the size lsd_shard_range gives comm->rank, else LSD_ERR_INVALID).  On `stream`, without host synchronisation:
+ *   1. the records are packed on the device, image-major, into a slab of cap_rows records (rows past the rank's lines are zero);
+ *   2. all-gather of the padded counts:  d_counts_all [world][per_rank + 2] int32 -- rank r's per-image counts (clamped to
+ *      max_lines, zero-padded), then [per_rank] = rows in its slab, [per_rank + 1] = 1 if it had to drop rows (more than cap_rows
+ *      lines, an image over max_lines, or an image the region stage gave up);
+ *   3. all-gather of the slabs:          d_slabs_all [world][cap_rows] lsd_line.
+ * Image g of the batch (rank r = its shard, local index j) has its lines at d_slabs_all[r][sum of counts[r][0..j)].
+ * ~22 MB per GPU and step for the 512 x 2048^2 bench batch at cap_rows = 512 per image. */
+int lsd_gather_lines(lsd_ctx *ctx, const lsd_comm *comm, const lsd_line *d_lines, const int32_t *d_counts, int n_local, int max_lines,
+                     int n_total, int cap_rows, int32_t *d_counts_all, lsd_line *d_slabs_all, void *stream);
+/* Host side of the hand-off: turns HOST copies of the two gathered arrays into offsets_out[n_total + 1] and (if lines_out is
+ * not NULL) the lines of all images in global image order (lines_cap records available).  LSD_ERR_CAPACITY if a rank flagged
+ * dropped rows (what arrived is still unpacked). */
+int lsd_gather_unpack(const int32_t *counts_all, const lsd_line *slabs_all, int n_total, int world, int cap_rows, int32_t *offsets_out,
+                      lsd_line *lines_out, size_t lines_cap);
+
 /* --- createMapCache (SURVEY 8f "next" #1) ------------------------------------------------------ */
 /* Replaces mylsd::createMapCache(Mat MapGray, double res) (LSD/myLSD.h:131, LSD/myLSD.cpp:11-127): distance (metres)
  * from every cell to the occupied cell (value 1) whose breadth-first flood reaches it first, capped at

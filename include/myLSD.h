@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -111,20 +112,32 @@ typedef struct _structLSD { /* LSD/myLSD.h:123-127 */
     int len_linesInfo;
 } structLSD;
 
-/* process-wide context on device LSD_DEVICE (default 0), created on first use */
-inline lsd_ctx* context() {
-    struct Holder {
-        lsd_ctx* c = nullptr;
-        int st = LSD_OK;
-        Holder() {
-            const char* d = std::getenv("LSD_DEVICE");
-            st = lsd_create(&c, d ? std::atoi(d) : 0);
-        }
-        ~Holder() { if (c) lsd_destroy(c); }
+/* One context per GPU, created on first use and kept for the life of the process.  context() without an argument is the calling
+ * thread's current device: set_device(d), else the environment variable LSD_DEVICE, else 0 -- so a host that drives several GPUs
+ * (one thread or one process per GPU) calls mylsd::set_device(rank) once per thread and the reference's own call
+ * sites stay as they are (LSD/main_on_windows.cpp:67-70). */
+inline int& current_device_ref() {
+    static thread_local int dev = -1;
+    return dev;
+}
+inline void set_device(int device) { current_device_ref() = device; }
+inline lsd_ctx* context(int device = -1) {
+    enum { kMaxDevices = 64 };
+    struct Table {
+        std::mutex mu;
+        lsd_ctx* c[kMaxDevices] = {};
+        ~Table() { for (lsd_ctx* p : c) if (p) lsd_destroy(p); }
     };
-    static Holder h;
-    if (h.st != LSD_OK) throw lsd_error(h.st, lsd_strerror(h.st));
-    return h.c;
+    static Table t;
+    if (device < 0) device = current_device_ref();
+    if (device < 0) { const char* d = std::getenv("LSD_DEVICE"); device = d ? std::atoi(d) : 0; }
+    if (device < 0 || device >= kMaxDevices) throw lsd_error(LSD_ERR_NO_DEVICE, lsd_strerror(LSD_ERR_NO_DEVICE));
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (!t.c[device]) {
+        const int st = lsd_create(&t.c[device], device);
+        if (st != LSD_OK) { t.c[device] = nullptr; throw lsd_error(st, lsd_strerror(st)); }
+    }
+    return t.c[device];
 }
 
 inline structLSD myLineSegmentDetector(Mat MapGray, int oriMapCol, int oriMapRow, double sca, double sig,

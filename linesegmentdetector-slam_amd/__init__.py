@@ -59,6 +59,14 @@ POS_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("ang", "f8")])
 SCORE_DTYPE = np.dtype([("x", "f8"), ("y", "f8"), ("ang", "f8"), ("score", "f8")])   # lsd_match_score
 
 
+# lsd_comm (include/lsd_hip.h): rank, world, an all-gather callback of device buffers on a stream, and its user pointer
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class lsd_comm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("all_gather", ALL_GATHER_FN), ("user", C.c_void_p)]
+
+
 class LsdError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("lsd_hip status %d: %s" % (status, msg))
@@ -124,6 +132,12 @@ def load_library(path=None):
         L.lsd_feature_scan_batch.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp]
         L.lsd_enqueue_feature_scan_batch_device.restype = i
         L.lsd_enqueue_feature_scan_batch_device.argtypes = [vp, vp, vp, i, i, lsd_map_param, i, dbl, dbl, vp, vp, vp, i, vp, vp, vp, vp]
+    if hasattr(L, "lsd_gather_lines") or not os.environ.get("LSD_HIP_LIB"):
+        L.lsd_shard_range.restype = None; L.lsd_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+        L.lsd_gather_layout.restype = i; L.lsd_gather_layout.argtypes = [i, i, C.POINTER(i), C.POINTER(sz)]
+        L.lsd_comm_from_rccl.restype = i; L.lsd_comm_from_rccl.argtypes = [vp, C.POINTER(lsd_comm)]
+        L.lsd_gather_lines.restype = i; L.lsd_gather_lines.argtypes = [vp, C.POINTER(lsd_comm), vp, vp, i, i, i, i, vp, vp, vp]
+        L.lsd_gather_unpack.restype = i; L.lsd_gather_unpack.argtypes = [vp, vp, i, i, i, vp, vp, sz]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -137,7 +151,40 @@ EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
-                    "lsd_feature_scan_batch", "lsd_enqueue_feature_scan_batch_device"]
+                    "lsd_feature_scan_batch", "lsd_enqueue_feature_scan_batch_device",
+                    "lsd_shard_range", "lsd_gather_layout", "lsd_comm_from_rccl", "lsd_gather_lines", "lsd_gather_unpack"]
+
+
+def shard_range(n_items, world, rank):
+    """lsd_shard_range: the contiguous shard [lo, hi) of n_items images that `rank` of `world` takes."""
+    lo, hi = C.c_int(), C.c_int()
+    load_library().lsd_shard_range(n_items, world, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def gather_layout(n_total, world):
+    """lsd_gather_layout -> (images of the largest shard, int32 words of the gathered counts array)."""
+    per, words = C.c_int(), C.c_size_t()
+    st = load_library().lsd_gather_layout(n_total, world, C.byref(per), C.byref(words))
+    if st != LSD_OK:
+        raise LsdError(st, load_library().lsd_strerror(st).decode())
+    return per.value, words.value
+
+
+def gather_unpack(counts_all, slabs_all, n_total, world, cap_rows):
+    """lsd_gather_unpack on HOST copies of the gathered arrays (int32 [world, per + 2], LINE_DTYPE / 80-byte records [world, cap_rows]):
+    returns (offsets int32 [n_total + 1], lines LINE_DTYPE in global image order); raises LsdError(LSD_ERR_CAPACITY) if a rank dropped rows."""
+    L = load_library()
+    ca = np.ascontiguousarray(counts_all, np.int32)
+    sl = np.ascontiguousarray(slabs_all).view(np.uint8).reshape(-1, 80)
+    offs = np.zeros(n_total + 1, np.int32)
+    per, _ = gather_layout(n_total, world)
+    total = int(ca.reshape(world, per + 2)[:, :per].sum())
+    lines = np.zeros(max(total, 1), LINE_DTYPE)
+    st = L.lsd_gather_unpack(ca.ctypes.data, sl.ctypes.data, n_total, world, cap_rows, offs.ctypes.data, lines.ctypes.data, len(lines))
+    if st != LSD_OK:
+        raise LsdError(st, L.lsd_strerror(st).decode())
+    return offs, lines[:offs[-1]]
 
 
 def make_params(sca=lsd_sca, sig=lsd_sig, angThre=lsd_angThre, denThre=lsd_denThre, pseBin=pseBin):
@@ -222,6 +269,11 @@ class Context:
         p = params or make_params()
         return self._chk(self.L.lsd_enqueue_batch_device(self.h, d_maps, n, cols, rows, C.byref(p), flags, d_line_ims,
                                                          d_lines, max_lines, d_counts, stream))
+
+    def gather_lines(self, comm, d_lines, d_counts, n_local, max_lines, n_total, cap_rows, d_counts_all, d_slabs_all, stream=None):
+        """lsd_gather_lines: comm is an lsd_comm (dist.torch_comm / lsd_comm_from_rccl); pointers are raw device addresses."""
+        return self._chk(self.L.lsd_gather_lines(self.h, C.byref(comm), d_lines, d_counts, n_local, max_lines, n_total, cap_rows,
+                                                 d_counts_all, d_slabs_all, stream))
 
     def map_cache(self, map_u8, res, z_occ_max_dis=1.0):
         """lsd_map_cache on a uint8 image (read-only); returns float64 [rows, cols]."""

@@ -81,6 +81,10 @@ struct lsd_ctx {
     size_t oc_cap = 0;
     uint8_t* mt_buf = nullptr;                          // staging of the host scan-to-map matching entry point
     size_t mt_cap = 0;
+    // lsd_gather_lines: this rank's padded counts + offsets, and its slab of packed line records
+    int32_t* ga_cnt = nullptr;
+    lsd_line* ga_slab = nullptr;
+    size_t ga_cnt_cap = 0, ga_slab_cap = 0;
     // options
     int stop_after = 0;
     bool trace = false;
@@ -369,7 +373,7 @@ void lsd_destroy(lsd_ctx* c) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
-                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf};
+                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf, c->ga_cnt, c->ga_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -892,6 +896,43 @@ int lsd_feature_scan_batch(lsd_ctx* c, const lsd_polar* scans, const int* lens, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n_scans; i++)
         if (n_lines[i] > LSD_RDP_MAX_LINES) return LSD_ERR_CAPACITY;      // more chords than the 360 records per scan hold (the first 360 are valid)
+    return LSD_OK;
+}
+
+int lsd_gather_lines(lsd_ctx* c, const lsd_comm* comm, const lsd_line* d_lines, const int32_t* d_counts, int n_local, int max_lines,
+                     int n_total, int cap_rows, int32_t* d_counts_all, lsd_line* d_slabs_all, void* stream) {
+    if (!c || !comm || !comm->all_gather || comm->world <= 0 || comm->rank < 0 || comm->rank >= comm->world || n_total <= 0 || n_local < 0 ||
+        max_lines <= 0 || cap_rows <= 0 || !d_counts_all || !d_slabs_all || (n_local > 0 && (!d_lines || !d_counts)))
+        return LSD_ERR_INVALID;
+    int lo, hi, per;
+    lsd_shard_range(n_total, comm->world, comm->rank, &lo, &hi);
+    if (hi - lo != n_local) return LSD_ERR_INVALID;                      // the caller's shard is not the one lsd_shard_range gives this rank
+    lsd_gather_layout(n_total, comm->world, &per, nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need_cnt = (size_t)(per + 2) + (size_t)(n_local > 0 ? n_local : 1);
+    if (need_cnt > c->ga_cnt_cap) {
+        c->ga_cnt_cap = 0;
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->ga_cnt, need_cnt));
+        c->ga_cnt_cap = need_cnt;
+    }
+    if ((size_t)cap_rows > c->ga_slab_cap) {
+        c->ga_slab_cap = 0;
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, re_alloc(&c->ga_slab, (size_t)cap_rows));
+        c->ga_slab_cap = (size_t)cap_rows;
+    }
+    // rows past this rank's lines are zero (nothing stale travels)
+    HIPCHK(c, hipMemsetAsync(c->ga_slab, 0, sizeof(lsd_line) * (size_t)cap_rows, s));
+    launch_pack_lines(d_lines, d_counts, n_local, max_lines, per, cap_rows, c->ga_cnt, c->ga_cnt + (per + 2), c->ga_slab, s);
+    HIPCHK(c, hipGetLastError());
+    if (comm->all_gather(comm->user, c->ga_cnt, d_counts_all, sizeof(int32_t) * (size_t)(per + 2), s) != 0 ||
+        comm->all_gather(comm->user, c->ga_slab, d_slabs_all, sizeof(lsd_line) * (size_t)cap_rows, s) != 0) {
+        c->err = "lsd_gather_lines: the communicator's all_gather failed";
+        return LSD_ERR_HIP;
+    }
+    c->last_stream = s;
     return LSD_OK;
 }
 

@@ -131,6 +131,8 @@ void launch_rdp(const double* scans, const int* lens, int n, int stride, int ori
                 double mapOriY, int region_point_limit, double thre_line, double line_dist_thre_m, lsd_line* lines_out, int* n_lines,
                 double* pts_out, int pts_cap, int* n_pts, double* lidar_pos, int* im_size, hipStream_t s);
 int rdp_max_len();
+void launch_pack_lines(const lsd_line* lines, const int32_t* counts, int n_local, int max_lines, int per, int cap_rows, int32_t* cpad,
+                       int32_t* offs, lsd_line* slab, hipStream_t s);
 void launch_dbgmath(int fn, const double* a, const double* b, double* o0, double* o1, size_t n, hipStream_t s);
 
 // x86-64 cvttsd2si semantics of the reference's (int) casts: NaN, +-inf and

@@ -99,6 +99,58 @@ def gather_line_lists(lines_i64, counts, n_total, dst=0, group=None, cap_rows=No
     return (None, None) if dense else (None, None, None)
 
 
+class _RawDeviceBytes:
+    """A raw device address as a __cuda_array_interface__ object: torch.as_tensor wraps it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def torch_comm(group=None):
+    """An lsd_comm (include/lsd_hip.h) over a torch.distributed process group: the callback the C ABI's lsd_gather_lines calls wraps
+    the raw device buffers and issues dist.all_gather_into_tensor (backend nccl = RCCL over xGMI) on the stream it is given.
+    Keep the returned object alive while the library may call it (it owns the ctypes callback)."""
+    import importlib
+    lsd = importlib.import_module(__package__)
+
+    def _all_gather(user, d_send, d_recv, nbytes, stream):
+        try:
+            world = dist.get_world_size(group)
+            send = torch.as_tensor(_RawDeviceBytes(d_send, nbytes), device="cuda")
+            recv = torch.as_tensor(_RawDeviceBytes(d_recv, nbytes * world), device="cuda")
+            st = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(recv, send, group=group)
+            return 0
+        except Exception:                                  # (an exception must not unwind through the C frames)
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    cb = lsd.ALL_GATHER_FN(_all_gather)
+    comm = lsd.lsd_comm(dist.get_rank(group), dist.get_world_size(group), cb, None)
+    comm._keepalive = cb
+    return comm
+
+
+def gather_lines_abi(ctx, comm, lines_i64, counts, n_total, cap_rows, stream=None):
+    """The C ABI's hand-off (lsd_gather_lines) on torch tensors: lines_i64 [n_local, max_lines, 10] int64 and counts [n_local] int32 of
+    this rank's shard -> (counts_all int32 [world, per + 2], slabs int64 [world, cap_rows, 10]) on every rank, enqueued on `stream`
+    (a raw hipStream_t / torch stream .cuda_stream; None: the current torch stream), no host synchronisation.  Same packing as
+    pack_lines() above; lsd.gather_unpack turns host copies of the two arrays into offsets + lines in global image order."""
+    import importlib
+    lsd = importlib.import_module(__package__)
+    per, _ = lsd.gather_layout(n_total, comm.world)
+    dev = lines_i64.device
+    counts_all = torch.empty((comm.world, per + 2), dtype=torch.int32, device=dev)
+    slabs = torch.empty((comm.world, cap_rows, WORDS_PER_LINE), dtype=torch.int64, device=dev)
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    ctx.gather_lines(comm, lines_i64.data_ptr(), counts.data_ptr(), counts.numel(), lines_i64.shape[1], n_total, cap_rows,
+                     counts_all.data_ptr(), slabs.data_ptr(), stream)
+    return counts_all, slabs
+
+
 def lines_to_numpy(lines_i64, line_dtype):
     """int64[total,10] -> structured numpy array with the structLinesInfo fields."""
     a = lines_i64.cpu().numpy()

@@ -220,9 +220,9 @@ def feature_scan(scan, map_param, region_point_limit=3, thre_line=0.08, line_dis
                             pts.ctypes.data, pts_cap, C.byref(npts), lidar.ctypes.data, size.ctypes.data)
     if rc != 0:
         raise RuntimeError("orc_feature_scan failed: %d" % rc)
-    assert npts.value <= pts_cap and nl.value <= 360
+    assert npts.value <= pts_cap                      # (nl may pass 360: the first 360 records are stored, as the HIP entry point does)
     pts = pts[:npts.value].copy()
     im = np.zeros((max(int(size[1]), 0), max(int(size[0]), 0)), np.uint8)
     if len(pts):
         im[pts[:, 1].astype(int), pts[:, 0].astype(int)] = 255
-    return dict(lines=lines[:nl.value].copy(), pts=pts, lidar_pos=(float(lidar[0]), float(lidar[1])), im_size=(int(size[0]), int(size[1])), lineIm=im)
+    return dict(lines=lines[:min(nl.value, 360)].copy(), n_lines=nl.value, pts=pts, lidar_pos=(float(lidar[0]), float(lidar[1])), im_size=(int(size[0]), int(size[1])), lineIm=im)

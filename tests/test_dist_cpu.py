@@ -110,6 +110,75 @@ def test_gather_line_lists_padded_form_world2(cap_rows, expect_over):
             assert len(dense) <= slabs.shape[1] and not slabs[r, len(dense):].any()
 
 
+def _pack_like_the_device(lines, counts, per, cap_rows):
+    """What lsd_gather_lines' device pack leaves on one rank (include/lsd_hip.h): cpad int32[per + 2] and a slab of cap_rows records
+    (10 int64 words each), image-major, rows past cap_rows dropped and flagged."""
+    n, max_lines, _ = lines.shape
+    c = np.clip(counts, 0, max_lines).astype(np.int32)
+    cpad = np.zeros(per + 2, np.int32)
+    cpad[:n] = c
+    dense = np.concatenate([lines[j, :c[j]] for j in range(n)] + [np.zeros((0, 10), np.int64)])
+    slab = np.zeros((cap_rows, 10), np.int64)
+    keep = min(len(dense), cap_rows)
+    slab[:keep] = dense[:keep]
+    cpad[per] = keep
+    cpad[per + 1] = 1 if (len(dense) > cap_rows or (counts > max_lines).any() or (counts < 0).any()) else 0
+    return cpad, slab
+
+
+@pytest.mark.parametrize("n_total,world,cap_rows,expect_over", [(7, 2, 64, False), (8, 2, 64, False), (1, 2, 8, False), (13, 3, 64, False), (7, 2, 6, True)])
+def test_c_abi_hand_off_host_side_with_a_host_memory_communicator(n_total, world, cap_rows, expect_over, lsdmod):
+    """The host side of the C ABI's multi-GPU hand-off (include/lsd_hip.h: lsd_shard_range, lsd_gather_layout, lsd_gather_unpack) for
+    world sizes 2 and 3 without a GPU: every rank's packed counts and slab (the documented layout of lsd_gather_lines' device pack)
+    go through a host-memory communicator -- an lsd_comm whose all_gather callback copies between the ranks' host buffers, called
+    through the same ctypes function-pointer type the library calls -- and lsd_gather_unpack must give the offsets and lines of the
+    whole batch in global image order.  An undersized slab is flagged (LSD_ERR_CAPACITY), never silent."""
+    import ctypes as C
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    per, words = lsdmod.gather_layout(n_total, world)
+    assert words == world * (per + 2)
+    ranks = []
+    for r in range(world):
+        lo, hi = lsdmod.shard_range(n_total, world, r)
+        assert (lo, hi) == ldist.shard_range(n_total, world, r)
+        lines, counts = _fake_shard(lo, hi, 8)
+        ranks.append(_pack_like_the_device(lines.numpy(), counts.numpy(), per, cap_rows))
+    # the host-memory communicator: rank r's callback finds every rank's send buffer in a table keyed by the collective's number
+    table = {}
+    recv = {r: [np.zeros((world, per + 2), np.int32), np.zeros((world, cap_rows, 10), np.int64)] for r in range(world)}
+    def make_comm(r):
+        calls = [0]
+        def all_gather(user, d_send, d_recv, nbytes, stream):
+            k = calls[0]; calls[0] += 1
+            for q in range(world):
+                src = table[(k, q)]
+                assert src.nbytes == nbytes
+                C.memmove(d_recv + q * nbytes, src.ctypes.data, nbytes)
+            return 0
+        cb = lsdmod.ALL_GATHER_FN(all_gather)
+        comm = lsdmod.lsd_comm(r, world, cb, None)
+        comm._keep = cb
+        return comm
+    for r, (cpad, slab) in enumerate(ranks):
+        table[(0, r)] = cpad; table[(1, r)] = slab
+    for r in range(world):
+        comm = make_comm(r)
+        assert comm.all_gather(None, ranks[r][0].ctypes.data, recv[r][0].ctypes.data, ranks[r][0].nbytes, None) == 0
+        assert comm.all_gather(None, ranks[r][1].ctypes.data, recv[r][1].ctypes.data, ranks[r][1].nbytes, None) == 0
+    exp_lines, exp_counts = _fake_shard(0, n_total, 8)
+    for r in range(world):                                   # every rank ends up with the same two arrays, and unpacks the same batch
+        assert np.array_equal(recv[r][0], recv[0][0]) and np.array_equal(recv[r][1], recv[0][1])
+        if expect_over:
+            with pytest.raises(lsdmod.LsdError) as e:
+                lsdmod.gather_unpack(recv[r][0], recv[r][1], n_total, world, cap_rows)
+            assert e.value.status == lsdmod.LSD_ERR_CAPACITY
+            continue
+        offs, lines = lsdmod.gather_unpack(recv[r][0], recv[r][1], n_total, world, cap_rows)
+        assert np.array_equal(offs, np.concatenate([[0], np.cumsum(exp_counts.numpy())]))
+        dense = np.concatenate([exp_lines[g, :exp_counts[g]].numpy() for g in range(n_total)] + [np.zeros((0, 10), np.int64)])
+        assert lines.view(np.int64).reshape(-1, 10).tobytes() == dense.tobytes()
+
+
 def test_shard_range_partitions():
     ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
     for n in (1, 5, 8, 512, 513):

@@ -777,6 +777,102 @@ def test_rccl_gather_runs_on_the_gpu(maps, lsdmod, ctx):
     assert int(out["lines_per_step"]) == len(lines) == int(offs[-1])
 
 
+def _fnv1a(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_c_abi_hand_off_over_rccl_from_a_cpp_host(maps, lsdmod, ctx, tmp_path):
+    """The multi-GPU hand-off as a C++ host calls it (include/lsd_hip.h: lsd_shard_range, lsd_comm_from_rccl, lsd_gather_lines,
+    lsd_gather_unpack; include/myLSD.h: set_device / context), in a fresh child process, over a real RCCL communicator of world
+    size 1 (tests/gather_host.cpp): offsets and the bytes of the line records equal those of run_batch on the same images."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "linesegmentdetector-slam_amd")
+    batch = bench.make_batch(maps, 5, 1024, 8)
+    raw = tmp_path / "batch.raw"
+    batch.tofile(raw)
+    exe = tmp_path / "gather_host"
+    subprocess.run(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(root, "tests", "gather_host.cpp"), "-o", str(exe), "-L", pkg, "-llsdhip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl",
+                    "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([str(exe), str(raw), "5", "1024", "1024"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    tok = [l for l in p.stdout.splitlines() if l.startswith("world")][-1].split()
+    assert tok[:6] == ["world", "1", "rank", "0", "per", "5"]
+    offs_got = [int(v) for v in tok[7:13]]
+    lines, offs, _ = ctx.run_batch(batch.copy(), want_lineim=False)
+    assert offs_got == offs.tolist() and offs_got[-1] > 100
+    assert int(tok[14]) == _fnv1a(lines.tobytes())
+
+
+def test_c_abi_hand_off_world2_on_one_gpu(maps, lsdmod, ctx):
+    """lsd_gather_lines with TWO ranks on the one GPU there is: two contexts, each running its lsd_shard_range shard of a 7-image
+    batch, and a communicator whose all_gather callback copies between the two ranks' device buffers (the same lsd_comm the RCCL
+    binding fills).  Both ranks end up with the same gathered arrays; unpacked, they are run_batch's answer for the whole batch,
+    in global image order.  A slab too small for a rank's lines is flagged on every rank."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ldist = importlib.import_module("linesegmentdetector-slam_amd.dist")
+    n_total, size, world, max_lines = 7, 1024, 2, 256
+    batch = bench.make_batch(maps, n_total, size, 40)
+    ref_lines, ref_offs, _ = ctx.run_batch(batch.copy(), want_lineim=False)
+    per, words = lsdmod.gather_layout(n_total, world)
+    ctxs = [lsdmod.Context(0) for _ in range(world)]
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for cap_rows, expect_over in ((n_total * 128, False), (100, True)):
+            calls = []                                           # (rank, collective number, d_send, d_recv, bytes)
+            def make_comm(r):
+                k = [0]
+                def all_gather(user, d_send, d_recv, nbytes, st):
+                    calls.append((r, k[0], d_send, d_recv, nbytes)); k[0] += 1
+                    return 0
+                cb = lsdmod.ALL_GATHER_FN(all_gather)
+                comm = lsdmod.lsd_comm(r, world, cb, None)
+                comm._keep = cb
+                return comm
+            outs = []
+            for r in range(world):
+                lo, hi = lsdmod.shard_range(n_total, world, r)
+                d = torch.from_numpy(batch[lo:hi]).cuda()
+                L = torch.zeros((hi - lo, max_lines, 10), dtype=torch.int64, device="cuda"); cnt = torch.zeros(hi - lo, dtype=torch.int32, device="cuda")
+                ctxs[r].enqueue_device(d.data_ptr(), hi - lo, size, size, L.data_ptr(), max_lines, cnt.data_ptr(), stream=stream)
+                ca = torch.zeros((world, per + 2), dtype=torch.int32, device="cuda"); sl = torch.zeros((world, cap_rows, 10), dtype=torch.int64, device="cuda")
+                ctxs[r].gather_lines(make_comm(r), L.data_ptr(), cnt.data_ptr(), hi - lo, max_lines, n_total, cap_rows, ca.data_ptr(), sl.data_ptr(), stream)
+                outs.append((ca, sl, d, L, cnt))
+            torch.cuda.synchronize()
+            # the "collective": rank q's send buffer of collective k lands at slot q of every rank's receive buffer
+            assert len(calls) == 2 * world
+            for (r, k, _, d_recv, nb) in calls:
+                for (q, k2, d_send, _, nb2) in calls:
+                    if k2 == k:
+                        assert nb2 == nb
+                        dst = torch.as_tensor(ldist._RawDeviceBytes(d_recv + q * nb, nb), device="cuda")
+                        dst.copy_(torch.as_tensor(ldist._RawDeviceBytes(d_send, nb), device="cuda"))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            ca, sl = outs[1][0].cpu().numpy(), outs[1][1].cpu().numpy()
+            if expect_over:
+                assert ca[:, per + 1].any()
+                with pytest.raises(lsdmod.LsdError) as e:
+                    lsdmod.gather_unpack(ca, sl, n_total, world, cap_rows)
+                assert e.value.status == lsdmod.LSD_ERR_CAPACITY
+            else:
+                offs, lines = lsdmod.gather_unpack(ca, sl, n_total, world, cap_rows)
+                assert np.array_equal(offs, ref_offs) and lines.tobytes() == ref_lines.tobytes()
+        with pytest.raises(lsdmod.LsdError):                     # a shard that is not this rank's
+            ctxs[0].gather_lines(make_comm(0), outs[1][3].data_ptr(), outs[1][4].data_ptr(), outs[1][4].numel(), max_lines, n_total, 64,
+                                 outs[0][0].data_ptr(), outs[0][1].data_ptr(), stream)
+    finally:
+        for c in ctxs: c.close()
+
+
 def test_feature_scan_batch_matches_oracle(lsdmod, ctx, oracle):
     """myrdp::FeatureScan for all 99 frames of data/Lidar.txt in ONE launch against the C restatement, frame by frame: line
     records (integers and the correctly rounded atand / cosd / sind: k, b, x, y, len, orient exact, dx / dy to 1e-15), the list of
@@ -806,6 +902,30 @@ def test_feature_scan_batch_matches_oracle(lsdmod, ctx, oracle):
     assert rdp_golden_check(got[int(z["matlab_frame"])], z) == (8, 711)
     one = lsdmod.FeatureScan(RDP_MAP_PARAM, scans[5, :lens[5]], ctx=ctx)
     assert np.array_equal(one["scanImPoint"], got[5]["scanImPoint"]) and one["linesInfo"].tobytes() == got[5]["linesInfo"].tobytes()
+
+
+def test_feature_scan_more_lines_than_the_reference_array_holds(lsdmod, ctx, oracle):
+    """A 1024-reading zigzag whose every reading becomes a split point gives ~1000 chords; the reference's array holds 360 (:39).
+    n_lines reports them all, the first 360 records are stored and equal the oracle's, the host entry point says LSD_ERR_CAPACITY."""
+    import ctypes as C
+    from test_oracle import RDP_MAP_PARAM
+    n = 1024
+    ang = np.linspace(-2.0, 2.0, n)
+    scan = np.stack([5.0 + 0.3 * (-1.0) ** np.arange(n), ang], 1)
+    ref = oracle.feature_scan(scan, RDP_MAP_PARAM, 3, 0.01, 0.0, pts_cap=65536)
+    assert ref["n_lines"] > 360 and len(ref["lines"]) == 360
+    with pytest.raises(lsdmod.LsdError) as e:
+        ctx.feature_scan_batch(scan[None], [n], RDP_MAP_PARAM, 3, 0.01, 0.0, pts_cap=65536)
+    assert e.value.status == lsdmod.LSD_ERR_CAPACITY
+    lines = np.zeros((1, 360), lsdmod.LINE_DTYPE); pts = np.zeros((1, 65536, 3)); nl = np.zeros(1, np.int32); npt = np.zeros(1, np.int32)
+    lp = np.zeros((1, 2)); sz = np.zeros((1, 2), np.int32); ln = np.array([n], np.int32)
+    mp = lsdmod.lsd_map_param(int(RDP_MAP_PARAM[0]), int(RDP_MAP_PARAM[1]), *[float(v) for v in RDP_MAP_PARAM[2:]])
+    st = ctx.L.lsd_feature_scan_batch(ctx.h, np.ascontiguousarray(scan).ctypes.data, ln.ctypes.data, 1, n, mp, 3, 0.01, 0.0, lines.ctypes.data, nl.ctypes.data,
+                                      pts.ctypes.data, 65536, npt.ctypes.data, lp.ctypes.data, sz.ctypes.data)
+    assert st == lsdmod.LSD_ERR_CAPACITY and nl[0] == ref["n_lines"] and npt[0] == len(ref["pts"])
+    lines["_pad"] = 0
+    assert lines[0].tobytes() == ref["lines"].tobytes()
+    assert np.array_equal(pts[0, :npt[0]], ref["pts"])
 
 
 @pytest.mark.parametrize("waves", [8, 4])
