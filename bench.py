@@ -143,16 +143,41 @@ def cpu_baseline(size, first, sample=24, reps=5):
     out["single_image_ms"] = min(t0s[1:]) * 1e3
     try:                                                            # N-core figure: N independent pinned instances over disjoint images
         import multiprocessing as mp
+        # how many cores this process may actually use: its affinity mask, cut down to the cgroup's CPU quota (a container that
+        # sees 256 CPUs but is given 16 CPUs' worth of time runs 256 pinned instances 16x slower each: the measured "collapse" of the
+        # all-cores figure in rounds 2-3) and to one hardware thread per physical core
+        quota = None
+        try:
+            q, per_us = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                quota = float(q) / float(per_us)
+        except (OSError, ValueError):
+            pass
+        sib = {}
+        for c_ in cores:
+            try:
+                key = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c_).read().strip()
+            except OSError:
+                key = str(c_)
+            sib.setdefault(key, c_)
+        phys = sorted(sib.values())
+        use = phys[:max(1, int(quota))] if quota and quota < len(phys) else phys
         per = max(4, sample // 3)
-        with mp.get_context("spawn").Pool(len(cores)) as pool:
-            t0 = time.perf_counter()
-            res = pool.map(_cpu_worker, [(c, first + sample + j * per, per, size, 1) for j, c in enumerate(cores)])
-            wall = time.perf_counter() - t0
+        def run_pool(cs):
+            with mp.get_context("spawn").Pool(len(cs)) as pool:
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_worker, [(c_, first + sample + j * per, per, size, 1) for j, c_ in enumerate(cs)])
+                return res, time.perf_counter() - t0
+        res, wall = run_pool(use)
         slowest = max(r[0][0] for r in res)                         # timed pass of the slowest instance (start-up excluded)
-        out["all_cores"] = {"cores": len(cores), "value": len(cores) * per * size * size / 1e6 / slowest, "unit": "Mpix/s",
-                            "lines_per_s": sum(r[1] for r in res) / slowest,
-                            "sample": "%d instances x %d images, each pinned to its core; slowest instance %.2f s (wall incl. start-up %.1f s)" % (
-                                len(cores), per, slowest, wall)}
+        val = len(use) * per * size * size / 1e6 / slowest
+        out["all_cores"] = {"cores": len(use), "value": val, "unit": "Mpix/s", "lines_per_s": sum(r[1] for r in res) / slowest,
+                            "per_core_vs_one_core": val / len(use) / out["value"],
+                            "host": {"logical_cpus_in_affinity_mask": len(cores), "physical_cores": len(phys), "cgroup_cpu_quota": quota},
+                            "sample": "%d instances x %d images, each pinned to its own physical core; slowest instance %.2f s (wall incl. start-up %.1f s).  "
+                                      "Cores = min(physical cores in the affinity mask, the cgroup's cpu.max quota): this container sees %d logical CPUs "
+                                      "but is given %s CPUs' worth of time, which is why one instance per visible CPU ran ~16-27x slower each in "
+                                      "rounds 2-3" % (len(use), per, slowest, wall, len(cores), "%.0f" % quota if quota else "all")}
     except Exception as e:                                          # (a sandbox without process spawning: the 1-core figure stands)
         out["all_cores"] = {"error": repr(e)}
     return out
@@ -227,6 +252,9 @@ def main():
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
     cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)
+    # the hand-off of the line lists goes through the C ABI (lsd_gather_lines: device pack + two all-gathers on the step's stream);
+    # its communicator is bound to the torch.distributed group here (RCCL), a C++ host binds it with lsd_comm_from_rccl
+    comm = ldist.torch_comm() if use_dist else None
 
     def step(i, collect):
         j = i % depth
@@ -236,7 +264,7 @@ def main():
         res = None
         if use_dist:
             with torch.cuda.stream(tstreams[j]):
-                res = ldist.gather_line_lists(l_, c_, n_total, dst=0, cap_rows=cap_rows, dense=False)
+                res = ldist.gather_lines_abi(ctxs[j], comm, l_, c_, n_total, cap_rows, stream=tstreams[j].cuda_stream)
         if collect:                                        # HIP events recorded on the launch stream by the library (this waits for the step)
             for k, v in ctxs[j].timings().items():
                 kt[k] += v
@@ -258,6 +286,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     last = outs[(a.steps - 1) % depth]
+    w_, h_ = lsd.scaled_size(size, size)
+    timed_cyc = np.array([ctxs[(a.steps - 1) % depth].fetch(i, lsd.DBG_STATS, (w_, h_))["cycles_total"] for i in range(n)], np.float64) if rank == 0 else None
     # One step at a time, after the timed region when that ran with several in flight: the per-kernel figures (inside an
     # overlapped region a launch's HIP events also time its wait for a CU) and the step time of a single batch, help on.
     un_steps, un_dt = a.steps, dt
@@ -286,8 +316,10 @@ def main():
 
     if rank == 0:
         if use_dist:                                       # the gathered result of the last step: every line arrived, nothing overflowed
-            cnts, slabs, over = res
-            assert int(cnts.sum().item()) == int(total_lines) and not bool(over.any().item()), "gather_line_lists lost lines"
+            counts_all, slabs = res
+            per, _ = lsd.gather_layout(n_total, world)
+            assert int(counts_all[:, :per].sum().item()) == int(total_lines) == int(counts_all[:, per].sum().item()), "lsd_gather_lines lost lines"
+            assert not bool(counts_all[:, per + 1].any().item()), "lsd_gather_lines: a slab overflowed"
         step_s = dt / a.steps
         mpix = n_total * size * size / 1e6
         grad_ms = kt["gradient"] / un_steps
@@ -323,7 +355,11 @@ def main():
                        "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU",
                        "rccl_gather_in_step": bool(use_dist),
-                       "steps_in_flight": depth, "region_waves_per_image": waves if waves else 8},
+                       "steps_in_flight": depth, "region_waves_per_image": waves if waves else 8,
+                       "help_across_workgroups": bool(depth == 1 or a.help_waves),
+                       # the steps in flight share one resident input, so the timed region runs WITHOUT LSD_FLAG_WRITEBACK_MAP: the
+                       # observable in-place remap of the caller's maps (myLSD.cpp:135-142; ~0.3 ms of byte writes per step) is not in it
+                       "writeback_map": False},
             # the timed region keeps `steps_in_flight` steps in flight (one context, stream and set of output buffers each);
             # `one_step_at_a_time` is the same step run alone, measured right after it -- the source of every per-kernel figure below
             "one_step_at_a_time": {"steps": un_steps, "ms_per_step": un_step_s * 1e3, "value": mpix / un_step_s, "unit": "Mpix/s",
@@ -343,7 +379,12 @@ def main():
             "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (un_step_s * 1e3),
                                 "Mpix_per_s": n * size * size / 1e6 / (reg_ms * 1e-3), "lines_per_s": float(d_counts.sum().item()) / (reg_ms * 1e-3),
                                 "bound": "serial dependence per image (no HBM / MFMA roofline applies): DESIGN.md section 4",
+                                "variant": "w8::k_region, help across workgroups on (the library's choice for one batch of this size)" if (depth > 1 or not waves) else "w%d::k_region" % waves,
                                 "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean())},
+                                # the same statistics for the last step of the TIMED region (its own variant; with several steps in flight a
+                                # workgroup shares its CU with workgroups of other steps, so these cycles include that contention)
+                                "timed_region": {"variant": "w%d::k_region, help %s, %d steps in flight" % (waves if waves else 8, "off" if (depth > 1 and not a.help_waves) else "on", depth),
+                                                 "cycles_per_image": {"mean": float(timed_cyc.mean()), "max": float(timed_cyc.max()), "max_over_mean": float(timed_cyc.max() / timed_cyc.mean())}},
                                 # full evaluations of the last step that wavefronts of finished workgroups did for other images
                                 "help_across_workgroups": {"evaluations": int(sum(x["help_evals"] for x in stats)),
                                                            "images_helped": int(sum(1 for x in stats if x["help_exports"] > 0))}},
@@ -352,7 +393,7 @@ def main():
                                   "note": "SURVEY 8d algorithmic bytes of the whole path (K1+K2+K3+K5; %.1f MB per image) over the step time" % (alg_img / 1e6)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total)
+            extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total, ctxs, outs, tstreams, waves)
             out["cpu_baseline"] = cb = cpu_baseline(size, first)
             # same-box ratios: the GPU against the single-thread port on THIS host's cores (cpu_baseline.kind = "port": a port of the
             # reference path that skips its two accidental full-image scans per region -- NOT the reference itself, which cannot
@@ -375,7 +416,7 @@ def main():
         c_.close()
 
 
-def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total):
+def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stream, dev, size, n_total, ctxs, outs, tstreams, waves):
     """Outside the timed region: what north_star asks for on mapValue_map1, single-image latency, device copy ceiling."""
     import torch
     ims = None if d_ims is None else d_ims.data_ptr()
@@ -445,7 +486,34 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
         for world in (2, 4, 8):
             ts = [run_shard(*ldist.shard_range(n_total, world, r)) for r in range(world)]
             proj[str(world)] = {"max_shard_ms": max(ts), "min_shard_ms": min(ts), "speedup": t_all / max(ts)}
-        out["strong_scaling_projection"] = {"gpus": proj, "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
+        # the same split in THROUGHPUT mode: what an N-GPU job sees when every rank keeps `depth` steps in flight on its shard
+        # (contexts ctxs[], 4-wave region stage, help off -- the configuration of this line's `value`), ms per sharded step
+        if len(ctxs) > 1:
+            def run_shard_pipelined(lo, hi, steps=8):
+                for c_ in ctxs:
+                    c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
+                def go(i):
+                    j = i % len(ctxs)
+                    l_, c2, im_ = outs[j]
+                    ctxs[j].enqueue_device(d_maps[lo:hi].data_ptr(), hi - lo, size, size, l_[lo:hi].data_ptr(), a.max_lines, c2[lo:hi].data_ptr(),
+                                           d_line_ims=None if im_ is None else im_[lo:hi].data_ptr(), stream=tstreams[j].cuda_stream)
+                for i in range(len(ctxs)):
+                    go(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(steps):
+                    go(i)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) * 1e3 / steps
+            t1_all = run_shard_pipelined(0, n_total)
+            proj["1"]["pipelined_ms_per_step"] = t1_all
+            for world in (2, 4, 8):
+                ts = [run_shard_pipelined(*ldist.shard_range(n_total, world, r)) for r in range(world)]
+                proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
+                                         "pipelined_speedup": t1_all / max(ts)})
+            ctx.set_region_help(-1); ctx.set_region_waves(0)
+        out["strong_scaling_projection"] = {"gpus": proj, "note_throughput_mode": "pipelined_*: every shard run with %d steps in flight (the timed region's configuration) on this one GPU; "
+                                            "a sharded job in throughput mode advances at its slowest shard's rate" % len(ctxs), "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
                                             "the sharded step takes at least its slowest shard: the region stage gives one CU per image, so a shard "
                                             "cannot finish before its heaviest image does" % n_total}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

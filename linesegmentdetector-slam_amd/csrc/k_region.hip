@@ -68,8 +68,15 @@ namespace RVAR {
 #endif
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
-constexpr int LCAP = 1024;   // region-list entries kept in LDS per wave; the rest spills to HBM
-constexpr int NT = 32;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words)
+#ifndef LSD_REGION_LCAP
+#define LSD_REGION_LCAP 1024
+#endif
+#ifndef LSD_REGION_NT
+#define LSD_REGION_NT 32
+#endif
+constexpr int LCAP = LSD_REGION_LCAP;   // region-list entries kept in LDS per wave; the rest spills to HBM
+constexpr int NT = LSD_REGION_NT;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words; a power of two)
+static_assert((NT & (NT - 1)) == 0 && NT >= 8 && LCAP >= 256 && (LCAP & 63) == 0, "tile slots: a power of two; list: whole 64-entry chunks");
 constexpr int RING = 128;    // remembered bounding boxes of recently accepted lines
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
@@ -149,9 +156,18 @@ constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
 // Per-wave LDS storage.  Declared at namespace scope (not inside the kernel) so that the out-of-line stages address it
 // as LDS (ds_ instructions) instead of through generic pointers carried in the context (flat_ instructions).
-__shared__ uint32_t g_lst[NW][LCAP];                      // region list (packed y<<16 | x), grow order
-__shared__ uint16_t g_wl[NW][2][LCAP + 2];                // sweep worklists (+ a dummy slot for predicated stores)
-__shared__ __attribute__((aligned(16))) uint32_t g_tw[NW][NT * 64];                    // tile cache: (fp32 angle & ~3) | member << 1 | banned
+// One arena of 32-bit words per wave, used in two ways.  A full evaluation: [region list, LCAP words (packed y<<16 | x, grow order)]
+// [two sweep worklists of LCAP + 2 16-bit entries (the last: a dummy slot for predicated stores)][tile cache, NT x 64 words:
+// (fp32 angle & ~3) | member << 1 | banned].  The small-region grower (seed loop): [eight 16x16-pixel windows][eight lists of
+// SCAP entries] from the start of the arena -- nothing of a full evaluation survives it (tw_small in the seed loop).
+constexpr int SCAP = 16;                  // list entries of a small-region group
+constexpr int kTwOff = (LCAP + (LCAP + 2) + 3) & ~3;         // (16-byte aligned: windows and tiles are written as uint4)
+constexpr int kSmallWords = 8 * 256 + 8 * SCAP;
+constexpr int kArenaWords = kTwOff + NT * 64 > kSmallWords ? kTwOff + NT * 64 : kSmallWords;
+__shared__ __attribute__((aligned(16))) uint32_t g_arena[NW][kArenaWords];
+#define G_LST(w) (&g_arena[w][0])
+#define G_WL(w, k) (reinterpret_cast<uint16_t*>(&g_arena[w][LCAP]) + (k) * (LCAP + 2))
+#define G_TW(w) (&g_arena[w][kTwOff])
 __shared__ int g_ttag[NW][NT];
 __shared__ unsigned long long g_stat[NW][kStatSlots];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
@@ -239,9 +255,9 @@ __device__ __forceinline__ float rlf(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return ((uint32_t)y << 16) | (uint32_t)x; }
-__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? g_lst[c.wave][i] : c.spill[i - LCAP]; }
+__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? G_LST(c.wave)[i] : c.spill[i - LCAP]; }
 __device__ __forceinline__ void lset(const RCtx& c, int i, uint32_t v) {
-    if (i < LCAP) g_lst[c.wave][i] = v; else c.spill[i - LCAP] = v;
+    if (i < LCAP) G_LST(c.wave)[i] = v; else c.spill[i - LCAP] = v;
 }
 __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp:540-542 / :1009-1011
     double d = fabs(a - b);
@@ -318,7 +334,7 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
         #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nt) {
-                g_tw[wave][S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
+                G_TW(wave)[S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
                 g_ttag[wave][S[j]] = T[j];                 // (all lanes, same value)
             }
         }
@@ -425,7 +441,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                 const uint32_t pk = lget(c, k2);
                 const int x = (int)(pk & 0xffffu), y = (int)(pk >> 16);
                 const int slot = tile_slot(x >> 3, y >> 3);
-                if (g_ttag[wave][slot] == tile_key(x >> 3, y >> 3)) g_tw[wave][slot * 64 + ((y & 7) << 3) + (x & 7)] &= ~2u;
+                if (g_ttag[wave][slot] == tile_key(x >> 3, y >> 3)) G_TW(wave)[slot * 64 + ((y & 7) << 3) + (x & 7)] &= ~2u;
             }
         }
     }
@@ -444,13 +460,13 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     double Ce, Se;                                           // estimated sum vector (fp64 accumulation of the fp32 unit vectors)
     {
         const int slot = tile_slot(sx >> 3, sy >> 3), ti = ((sy & 7) << 3) | (sx & 7);
-        const uint32_t sw = g_tw[wave][slot * 64 + ti];
+        const uint32_t sw = G_TW(wave)[slot * 64 + ti];
         float s0, c0;
         fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
         Ce = (double)c0; Se = (double)s0;
         if (lane == 0) {
-            g_lst[wave][0] = pack_xy(sx, sy);
-            g_tw[wave][slot * 64 + ti] = sw | 2u;            // :520
+            G_LST(wave)[0] = pack_xy(sx, sy);
+            G_TW(wave)[slot * 64 + ti] = sw | 2u;            // :520
             stamp[sy * w + sx] = id;
             g_ws[wave].dirty = 1;
         }
@@ -493,7 +509,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         // (entries past n: harmless garbage, masked by valid.)  The LDS part of the list is read unconditionally and the HBM part
         // in a block of its own that also waits for it: a load whose register is still pending at the join would make the
         // compiler put an s_waitcnt vmcnt(0) in front of every batch, and that waits for the stamp stores of the batch before.
-        uint32_t pk = g_lst[wave][direct ? eidx : min(eidx, LCAP - 1)];
+        uint32_t pk = G_LST(wave)[direct ? eidx : min(eidx, LCAP - 1)];
         if (!direct && ballot64(valid & (eidx >= LCAP))) {
             uint32_t t = pk;
             if (valid & (eidx >= LCAP)) t = c.spill[eidx - LCAP];
@@ -505,7 +521,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         const int tx = nx >> 3, ty = ny >> 3;
         const int slot = tile_slot(tx, ty);
         const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
-        uint32_t word_r = g_tw[wave][cell];
+        uint32_t word_r = G_TW(wave)[cell];
         const int tagv = g_ttag[wave][slot];
         if (ballot64(inb & (tagv != tile_key(tx, ty)))) {
             if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
@@ -514,7 +530,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                 inb = inb && valid;
                 ensure_tiles(c, inb, nx, ny);
             }
-            word_r = g_tw[wave][cell];
+            word_r = G_TW(wave)[cell];
         }
         const bool cand = inb & ((word_r & 3u) == 0u);   // :537: not in curMap, not banned (2 is growable, Q5)
         const unsigned long long candm = ballot64(cand);
@@ -554,9 +570,9 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     const int np = __builtin_popcountll(P);
                     if ((P >> lane) & 1ull) {
                         const int idx = n + mbcnt(P);
-                        g_tw[wave][cell] = word_r | 2u;                           // :549
+                        G_TW(wave)[cell] = word_r | 2u;                           // :549
                         stamp[(uint32_t)q] = id;
-                        if (n + 64 <= LCAP) g_lst[wave][idx] = pack_xy(nx, ny);   // :551-556
+                        if (n + 64 <= LCAP) G_LST(wave)[idx] = pack_xy(nx, ny);   // :551-556
                         else lset(c, idx, pack_xy(nx, ny));
                     }
                     float ps = 0.0f, pc2 = 0.0f;
@@ -622,7 +638,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     }
                     if (decided == 1) {
                         if (lane == l) {
-                            g_tw[wave][cell] = word_r | 2u;                       // :549
+                            G_TW(wave)[cell] = word_r | 2u;                       // :549
                             stamp[(uint32_t)q] = id;
                             lset(c, n, pack_xy(nx, ny));                          // :551-556
                         }
@@ -657,7 +673,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                 const unsigned long long hm = ballot64(has & (k == 0));
                 const int add = __builtin_popcountll(hm);
                 const bool room = nxt_cnt + add <= LCAP && n <= 65535;
-                g_wl[wave][wcur ^ 1][(room & has & (k == 0)) ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
+                G_WL(wave, wcur ^ 1)[(room & has & (k == 0)) ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
                 filter = filter && room;
                 nxt_cnt += room ? add : 0;
             }
@@ -697,7 +713,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         flt_base = wi;
                         bool nd = false;
                         if (wi + lane < wl_cnt) {
-                            const int ei = (int)g_wl[wave][wcur][wi + lane];
+                            const int ei = (int)G_WL(wave, wcur)[wi + lane];
                             nd = true;
                             if (ei < mcap) {
                                 const nf4 mt = meta[(uint32_t)ei];
@@ -716,7 +732,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     if (nskip > 0) {                         // a run of entries that cannot accept anything: carry them over
                         // (lane-dependent branches stay in the MIDDLE of wave-uniform blocks, see STAT)
                         const bool room = nxt_cnt + nskip <= LCAP;
-                        g_wl[wave][wcur ^ 1][room && lane < nskip ? nxt_cnt + lane : LCAP] = g_wl[wave][wcur][min(wi + lane, LCAP - 1)];   // (no branch: dummy slot)
+                        G_WL(wave, wcur ^ 1)[room && lane < nskip ? nxt_cnt + lane : LCAP] = G_WL(wave, wcur)[min(wi + lane, LCAP - 1)];   // (no branch: dummy slot)
                         filter = filter && room;
                         nxt_cnt += room ? nskip : 0;
                         wi += nskip;
@@ -726,7 +742,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     const unsigned long long inv = ~rest;
                     cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
                 }
-                const int eidx = e < cnt ? (int)g_wl[wave][wcur][wi + e] : 0;
+                const int eidx = e < cnt ? (int)G_WL(wave, wcur)[wi + e] : 0;
                 wi += batch(cnt, eidx, false, Cf, Sf, rV, Vn, nrat);
             }
         }
@@ -877,7 +893,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
     bool removed_any = false;
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
     unsigned long long* const msk = reinterpret_cast<unsigned long long*>(g_acc[wave]);   // keep-masks of up to 128 chunks of 64 entries
-    uint32_t* const mv = reinterpret_cast<uint32_t*>(&g_wl[wave][0][0]);                   // up to 1024 moved entries (the worklists are free here)
+    uint32_t* const mv = reinterpret_cast<uint32_t*>(G_WL(wave, 0));                       // up to LCAP moved entries (the worklists are free here)
     while (den < denThre) {                                                        // :775
         rad *= 0.75;
         STAT(ST_RRRPASS, 1);
@@ -901,7 +917,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                 msk[ci] = nearm;                           // (all lanes, same value)
                 K += __builtin_popcountll(nearm);
             }
-            if (min(K, num - K) > 1024) parallel = false;  // more moves than mv[] holds
+            if (min(K, num - K) > LCAP) parallel = false;  // more moves than mv[] holds
         }
         if (parallel) {
             if (K != num) {
@@ -911,7 +927,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                     const bool is = (((msk[ci] >> lane) & 1ull) != 0ull) & (idx >= K);
                     const unsigned long long mm = ballot64(is);
                     const int above = __builtin_popcountll((mm >> lane) >> 1);
-                    mv[is ? nm + above : 1024] = is ? lget(c, idx) : 0u;           // (no branch: dummy slot; g_wl has 2 spare entries = 1 word)
+                    mv[is ? nm + above : LCAP] = is ? lget(c, idx) : 0u;           // (no branch: dummy slot; the worklists have 2 spare entries each = 2 words)
                     nm += __builtin_popcountll(mm);
                 }
                 int nh = 0;                                // far points of the slots < K, lowest slot first
@@ -1025,7 +1041,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
     int all = 0, ali = 0;
     // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
-    int* const s_incl = reinterpret_cast<int*>(&g_wl[c.wave][0][0]);
+    int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave, 0));
     int* const s_lo = s_incl + 64;
     int* const s_x = s_incl + 128;
     for (int cb = 0; cb < xlen; cb += 64) {
@@ -1399,8 +1415,6 @@ enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5
 constexpr int kHelpIdle = 50;             // looks without a request after which a helper wavefront leaves an image
 constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
 constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
-
-constexpr int SCAP = 16;                  // list entries of a small-region group
 
 struct Ring {
     alignas(4) uint8_t state[RW];
@@ -1941,14 +1955,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(G
     int ncap = 1;                                           // a group gives its seed up when the region reaches ncap pixels
     if (g.regThre > 1.0 && g.degThre < 1.5) ncap = g.regThre >= (double)SCAP ? SCAP : (int)ceil(g.regThre);
     const float cos_tol_s = (float)g_tol0[2];
-    uint32_t* const swin = &g_tw[wave][grp * 256];          // this group's window (the tile cache is not in use meanwhile)
-    uint32_t* const slst = &g_lst[wave][grp * SCAP];        // this group's list: ly << 4 | lx
+    uint32_t* const swin = &g_arena[wave][grp * 256];       // this group's window (the arena holds no full evaluation meanwhile)
+    uint32_t* const slst = &g_arena[wave][8 * 256 + grp * SCAP];   // this group's list: ly << 4 | lx
     int gk = -1;                                            // seed of this lane's group, -1: idle
     int gn = 0, gi = 0, gex = 0, gwx = 0, gwy = 0, gsnap = 0;
     float gC = 0.0f, gS = 0.0f;                             // estimated sum vector of the group's region
     int ch_k0 = 0, ch_sx = 0, ch_sy = 0;                    // the wave's chunk: lane j < CH holds seed ch_k0 + j
     unsigned long long ch_pend = 0ull;                      // seeds of the chunk not handed to a group yet
-    bool tw_small = false;                                  // g_tw / g_lst hold windows and small lists (not tiles / a region list)
+    bool tw_small = false;                                  // the arena holds windows and small lists (not tiles / a region list)
     constexpr float kEpsS = 1.0e-5f;                        // kEpsU + the fp32 running sums of up to SCAP unit vectors
 
     int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done

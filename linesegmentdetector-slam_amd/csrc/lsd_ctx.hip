@@ -469,9 +469,9 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));
     HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, s));
     HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * n, s));
-    if (d_line_ims) HIPCHK(c, hipMemsetAsync(d_line_ims, 0, (size_t)n * cols * rows, s));   // Mat::zeros, myLSD.cpp:215
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (d_line_ims) launch_clear(d_line_ims, (size_t)n * cols * rows, c->num_cus, s);        // Mat::zeros, myLSD.cpp:215 (inside the event window: part of "gauss")
     launch_gauss(g, b, n, s);
     if (b.in_rw) launch_remap_writeback(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[1], s));

@@ -126,6 +126,7 @@ void launch_mapcache_spread(const uint8_t* maps, double* out, unsigned long long
 void launch_mapcache(const uint8_t* maps, double* out, unsigned long long* claim, uint32_t* fr_a, uint32_t* fr_b, int n,
                      int W, int H, double res, double zmax, int cell_radius, hipStream_t s);
 void launch_lines(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_clear(uint8_t* p, size_t bytes, int num_cus, hipStream_t s);   // lineIm = zeros (k_lines.hip)
 void launch_compact_lines(const lsd_line* lines, const int32_t* counts, int max_lines, int n, lsd_line* flat, int32_t* offsets, hipStream_t s);
 void launch_rdp(const double* scans, const int* lens, int n, int stride, int oriMapCol, int oriMapRow, double mapResol, double mapOriX,
                 double mapOriY, int region_point_limit, double thre_line, double line_dist_thre_m, lsd_line* lines_out, int* n_lines,

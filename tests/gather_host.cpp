@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     size_t words;
     lsd_shard_range(n, lc.world, lc.rank, &lo, &hi);
     CK(lsd_gather_layout(n, lc.world, &per, &words));
-    const int n_local = hi - lo, max_lines = 256, cap_rows = n * 64;
+    const int n_local = hi - lo, max_lines = 256, cap_rows = n * 256;
 
     hipStream_t s;
     CK(hipStreamCreate(&s));
