@@ -59,6 +59,9 @@ namespace RVAR {
 #ifndef LSD_REGION_NS
 #define LSD_REGION_NS 16
 #endif
+#ifndef LSD_REGION_KATTR
+#define LSD_REGION_KATTR                 // experiments: extra attributes of the kernel (e.g. __attribute__((amdgpu_num_vgpr(168))))
+#endif
 #ifndef LSD_REGION_WAIT_SLEEP
 #define LSD_REGION_WAIT_SLEEP 127      // x 64 clocks
 #endif
@@ -152,6 +155,15 @@ constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 #else
 #define DSTAT(i, v) do { } while (0)
 #define NOW() 0ll
+#endif
+// developer experiment (with LSD_REGION_STATS): the time of one grow() batch by segment, in the counters of the per-stage stopwatches
+// (rect: entry -> neighbour words read; nfa: -> classified; mark: -> accepted; refine: -> worklist done; sums: between batches)
+#ifdef LSD_REGION_BATCHPROF
+#define BSTAT(i, v) DSTAT(i, v)
+#define PSTAT(i, v) do { } while (0)
+#else
+#define BSTAT(i, v) do { } while (0)
+#define PSTAT(i, v) DSTAT(i, v)
 #endif
 
 // Per-wave LDS storage.  Declared at namespace scope (not inside the kernel) so that the out-of-line stages address it
@@ -381,7 +393,7 @@ __device__ __noinline__ void exact_sums(int cw_, int n_) {
     }
     if (lane == 0) { g_ws[wave].ex_cos = S; g_ws[wave].ex_upto = n; }
     if (lane == 1) g_ws[wave].ex_sin = S;
-    DSTAT(ST_TSUMS, NOW() - t0);
+    PSTAT(ST_TSUMS, NOW() - t0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -501,10 +513,13 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     int flt_base = 0;
     bool flt_valid = false;
     int nxt_cnt = 0;                                         // entries of the next sweep's worklist
+    [[maybe_unused]] long long bt_last = NOW();
     // One batch: up to 8 list entries (cnt of them, entry e of the batch = list index eidx in its 8 lanes) x 8 neighbours.
     // Returns the number of entries it dealt with (1 instead of cnt when their tiles collide in the cache).
     auto batch = [&](int cnt, const int eidx, const bool direct, const float Cf, const float Sf, const float rV, const float Vn,
                      const float nrat) -> int {
+        [[maybe_unused]] const long long bt0 = NOW();
+        BSTAT(ST_TSUMS, bt0 - bt_last);
         bool valid = e < cnt;
         // (entries past n: harmless garbage, masked by valid.)  The LDS part of the list is read unconditionally and the HBM part
         // in a block of its own that also waits for it: a load whose register is still pending at the join would make the
@@ -535,6 +550,9 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         const bool cand = inb & ((word_r & 3u) == 0u);   // :537: not in curMap, not banned (2 is growable, Q5)
         const unsigned long long candm = ballot64(cand);
         DSTAT(ST_BATCHES, 1);
+        [[maybe_unused]] const long long bt1 = NOW();
+        BSTAT(ST_TRECT, bt1 - bt0);
+        [[maybe_unused]] long long bt2 = bt1, bt3 = bt1;
         if (candm) {
             const int q = ny * w + nx;
             const float af = __uint_as_float(word_r & ~3u);
@@ -553,6 +571,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
             unsigned long long gone = 0;                 // every lane whose pixel became a member in this batch
             bool bulk = false;
             float dot = 0.0f;
+            bt2 = NOW();
+            BSTAT(ST_TNFA, bt2 - bt1);
             if (tol_small) {
                 const float m = (float)__builtin_popcountll(ballot64(winner));
                 dot = __builtin_fmaf(cf, Cf, sf * Sf);                            // ~ cos(distance) * |V|
@@ -650,6 +670,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     }
                 }
             }
+            bt3 = NOW();
+            BSTAT(ST_TMARK, bt3 - bt2);
             // entries that still have a growable non-member neighbour go to the next sweep's worklist
             const unsigned long long left = candm & ~gone;
             if (filter && left) {
@@ -677,7 +699,9 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                 filter = filter && room;
                 nxt_cnt += room ? add : 0;
             }
+            BSTAT(ST_TREFINE, NOW() - bt3);
         }
+        bt_last = NOW();
         return cnt;
     };
     // The loop state is wave-uniform by construction, but the compiler's divergence analysis gives up on it as soon as the
@@ -855,7 +879,7 @@ __device__ __noinline__ void rect_convert(int cw_, int num, double regdeg, doubl
         r.p = aliPro; r.prec = tol; r.pk = pk;
         if (r.wid < 1) r.wid = 1;                                                  // :730
     }
-    DSTAT(ST_TRECT, NOW() - t0);
+    PSTAT(ST_TRECT, NOW() - t0);
 }
 
 __device__ __forceinline__ double rec_density(int num, const Rec& r) {             // :757,:798,:827,:867
@@ -1114,7 +1138,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
 __device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec) {
     [[maybe_unused]] const long long t0 = NOW();
     const double v = rect_nfa_impl(c, rec);
-    DSTAT(ST_TNFA, NOW() - t0);
+    PSTAT(ST_TNFA, NOW() - t0);
     return v;
 }
 
@@ -1202,7 +1226,7 @@ __device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, doub
     }
     const double difSum = rl(S, 0), squSum = rl(S, 1);
     const double meanDif = difSum / (ptNum * 1.0);
-    DSTAT(ST_TREFINE, NOW() - t0);
+    PSTAT(ST_TREFINE, NOW() - t0);
     return 2.0 * sqrt((squSum - 2 * meanDif * difSum) / (ptNum * 1.0) + meanDif * meanDif);   // :855
 }
 
@@ -1239,7 +1263,7 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
         x0 = min(x0, __shfl_xor(x0, off)); y0 = min(y0, __shfl_xor(y0, off));
         x1 = max(x1, __shfl_xor(x1, off)); y1 = max(y1, __shfl_xor(y1, off));
     }
-    DSTAT(ST_TMARK, NOW() - t0);
+    PSTAT(ST_TMARK, NOW() - t0);
     Box bx; bx.x0 = x0; bx.y0 = y0; bx.x1 = x1; bx.y1 = y1;
     return bx;
 }
@@ -1444,7 +1468,7 @@ __device__ __forceinline__ bool st_cas(uint8_t* base, int idx, int expect, int d
 __device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
 __device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
-__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) void k_region(Geom g, Buffers b, uint32_t id_base) {
+__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATTR void k_region(Geom g, Buffers b, uint32_t id_base) {
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# developer probe: SQ counters (instruction mix, instruction cache, issue / wait) of the region stage over the WHOLE bench batch run as
+# one step on the 4-wave build (512 workgroups resident, two per CU: the loaded regime)     tools/pmc_batch.sh <tag> [waves]
+tag=$1; waves=${2:-4}
+cd /tmp && export TMPDIR=/tmp
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  n=$(echo $set | cut -d' ' -f1)
+  out=$GRAFT_REPO_ROOT/gpurun_out/pmc_batch_${tag}_$n
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o pmc -- python3 $GRAFT_REPO_ROOT/tools/breakdown.py $waves 512 > $out.log 2>&1
+  python3 - <<PY
+import csv, glob, collections
+f = glob.glob("$out/**/*counter_collection.csv", recursive=True)
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for p in f:
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"].split("(")[0][-40:]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+for k, d in agg.items():
+    if "region" in k:
+        print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
+PY
+  grep "region" $out.log | head -2
+done
