@@ -26,6 +26,11 @@ import time
 
 import numpy as np
 
+# Throughput mode keeps several steps in flight, one stream each; the HIP runtime maps streams onto 4 hardware queues unless told
+# otherwise, and streams that share a queue run their kernels one after the other.  One queue per step in flight (read when the
+# runtime initialises, i.e. before torch touches the GPU).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -195,7 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip everything outside the timed region (CPU baseline, map1 targets, single-image latency, copy ceiling): what the profiling passes use")
     ap.add_argument("--no-lineim", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="exercise the RCCL gather path even with one rank (testing)")
-    ap.add_argument("--pipeline", type=int, default=4, help="steps in flight: step i runs on context / stream i %% depth, so that the tail of one step's region stage "
+    ap.add_argument("--pipeline", type=int, default=8, help="steps in flight: step i runs on context / stream i %% depth, so that the tail of one step's region stage "
                     "(a few images on a CU each) overlaps the head of the next one's; 1 = one step at a time")
     ap.add_argument("--waves", type=int, default=-1, choices=(-1, 0, 4, 8), help="wavefronts per image of the region stage in the timed region: 0 = the library's choice "
                     "(8 for this batch size: lowest latency of one batch), 4 = two images per CU (highest throughput per CU); -1 = 4 with several steps in flight, else 0")
@@ -245,10 +250,10 @@ def main():
     d_lines, d_counts, d_ims = outs[0]
     stream = tstreams[0].cuda_stream
     for c_ in ctxs:
-        c_.reserve(n, size, size)
         if depth > 1:
             c_.set_region_help(a.help_waves)
-        c_.set_region_waves(waves)
+        c_.set_region_waves(waves)                          # (before reserve: the per-wave workspace is sized for the variant)
+        c_.reserve(n, size, size)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
     cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)

@@ -72,14 +72,19 @@ namespace RVAR {
 constexpr int NW = LSD_REGION_NW;        // wavefronts (concurrent speculative seeds) per image
 constexpr int NS = LSD_REGION_NS;        // result slots per wave: seeds a wave may have evaluated ahead of the cursor
 #ifndef LSD_REGION_LCAP
-#define LSD_REGION_LCAP 1024
+#define LSD_REGION_LCAP 512
 #endif
 #ifndef LSD_REGION_NT
-#define LSD_REGION_NT 32
+#define LSD_REGION_NT 16
 #endif
-constexpr int LCAP = LSD_REGION_LCAP;   // region-list entries kept in LDS per wave; the rest spills to HBM
-constexpr int NT = LSD_REGION_NT;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words; a power of two)
-static_assert((NT & (NT - 1)) == 0 && NT >= 8 && LCAP >= 256 && (LCAP & 63) == 0, "tile slots: a power of two; list: whole 64-entry chunks");
+// The region list of a grow lives in LDS as a RING of the LCAP entries appended last (slot = index mod LCAP): the sweep that appends
+// entries reads them again a frontier's width later, which for the thin structures of an occupancy map is a handful of entries,
+// whatever the length of the region.  A list that outgrows the ring is also written through to HBM (`spill`, all entries, from the
+// moment the ring would wrap), where the few readers of older entries find them (re-sweeps, the sums over the whole list).
+constexpr int LCAP = LSD_REGION_LCAP;   // entries of the list ring (a power of two)
+constexpr int LMASK = LCAP - 1;
+constexpr int NT = LSD_REGION_NT;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words; a power of two; 16 measured as good as 32)
+static_assert((NT & (NT - 1)) == 0 && NT >= 8 && LCAP >= 256 && (LCAP & (LCAP - 1)) == 0, "tile slots and list ring: powers of two");
 constexpr int RING = 128;    // remembered bounding boxes of recently accepted lines
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
@@ -122,6 +127,7 @@ struct RCtx {
     const double* ptab;
     uint32_t* wslist;    // this wave's result slots: [NS][gcap] list entries
     int gcap;
+    int llo;             // entries [llo, n) of the current region list are in the LDS ring, entries below in `spill` (grow() keeps g_ctx[wave].llo current)
 };
 
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
@@ -168,17 +174,25 @@ constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
 
 // Per-wave LDS storage.  Declared at namespace scope (not inside the kernel) so that the out-of-line stages address it
 // as LDS (ds_ instructions) instead of through generic pointers carried in the context (flat_ instructions).
-// One arena of 32-bit words per wave, used in two ways.  A full evaluation: [region list, LCAP words (packed y<<16 | x, grow order)]
-// [two sweep worklists of LCAP + 2 16-bit entries (the last: a dummy slot for predicated stores)][tile cache, NT x 64 words:
-// (fp32 angle & ~3) | member << 1 | banned].  The small-region grower (seed loop): [eight 16x16-pixel windows][eight lists of
-// SCAP entries] from the start of the arena -- nothing of a full evaluation survives it (tw_small in the seed loop).
+// One arena of 32-bit words per wave, used in two ways.  A full evaluation: [list ring, LCAP words (packed y<<16 | x)][the sweep
+// worklist, WCAP 16-bit entries + a dummy slot for predicated stores: list indices of the entries that still have a growable
+// neighbour; the next sweep's worklist is written IN PLACE behind the read cursor][tile cache, NT x 64 words: (fp32 angle & ~3) |
+// member << 1 | banned].  The small-region grower (seed loop): [eight 16x16-pixel windows][eight lists of SCAP entries] from the
+// start of the arena -- nothing of a full evaluation survives it (tw_small in the seed loop).
 constexpr int SCAP = 16;                  // list entries of a small-region group
-constexpr int kTwOff = (LCAP + (LCAP + 2) + 3) & ~3;         // (16-byte aligned: windows and tiles are written as uint4)
 constexpr int kSmallWords = 8 * 256 + 8 * SCAP;
+#ifndef LSD_REGION_WLW
+#define LSD_REGION_WLW (kSmallWords - LCAP - NT * 64 >= 256 ? kSmallWords - LCAP - NT * 64 : 256)
+#endif
+constexpr int WLW = (LSD_REGION_WLW + 3) & ~3;               // words of the worklist (16-byte multiple: windows and tiles are written as uint4)
+constexpr int WCAP = 2 * WLW - 2;                            // its entries; [WCAP]: the dummy slot
+constexpr int kTwOff = LCAP + WLW;
 constexpr int kArenaWords = kTwOff + NT * 64 > kSmallWords ? kTwOff + NT * 64 : kSmallWords;
+constexpr int kMvCap = kArenaWords - LCAP - 1;               // RegionRadiusReducer's scratch: worklist + tile cache (+ a dummy slot)
+static_assert(WLW >= 192, "the NFA's column scan keeps 3 x 64 ints in the worklist's place");
 __shared__ __attribute__((aligned(16))) uint32_t g_arena[NW][kArenaWords];
 #define G_LST(w) (&g_arena[w][0])
-#define G_WL(w, k) (reinterpret_cast<uint16_t*>(&g_arena[w][LCAP]) + (k) * (LCAP + 2))
+#define G_WL(w) (reinterpret_cast<uint16_t*>(&g_arena[w][LCAP]))
 #define G_TW(w) (&g_arena[w][kTwOff])
 __shared__ int g_ttag[NW][NT];
 __shared__ unsigned long long g_stat[NW][kStatSlots];      // per-wave counters (see ST_* above); kept out of registers
@@ -267,9 +281,9 @@ __device__ __forceinline__ float rlf(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ uint32_t pack_xy(int x, int y) { return ((uint32_t)y << 16) | (uint32_t)x; }
-__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i < LCAP ? G_LST(c.wave)[i] : c.spill[i - LCAP]; }
-__device__ __forceinline__ void lset(const RCtx& c, int i, uint32_t v) {
-    if (i < LCAP) G_LST(c.wave)[i] = v; else c.spill[i - LCAP] = v;
+__device__ __forceinline__ uint32_t lget(const RCtx& c, int i) { return i >= c.llo ? G_LST(c.wave)[i & LMASK] : c.spill[i]; }
+__device__ __forceinline__ void lset(const RCtx& c, int i, uint32_t v) {           // (after the grow: every entry has one home)
+    if (i >= c.llo) G_LST(c.wave)[i & LMASK] = v; else c.spill[i] = v;
 }
 __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp:540-542 / :1009-1011
     double d = fabs(a - b);
@@ -467,7 +481,10 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     if (lane == 0) {
         WState& ws = g_ws[wave];
         ws.cur_id = id; ws.members_cached = 1; ws.has_copy = 0; ws.ex_upto = 0; ws.ex_sin = 0.0; ws.ex_cos = 0.0;
+        g_ctx[wave].llo = 0;                                 // the new list starts inside the ring
     }
+    c.llo = 0;
+    AS1 uint32_t* const spill = uglobal(c.spill);
     ensure_tiles(c, lane == 0, sx, sy);
     double Ce, Se;                                           // estimated sum vector (fp64 accumulation of the fp32 unit vectors)
     {
@@ -484,6 +501,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         }
     }
     int n = 1;
+    bool wt = false;                                         // the list has outgrown the ring: entries are also written through to `spill`
     if (!(tol == tol)) {                                     // NaN tolerance (Refiner, :855): no test ever passes
         if (lane == 0) g_ws[wave].gnum = 1;
         STAT(ST_GROW, 1); STAT(ST_GROWN, 1);
@@ -502,9 +520,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     const int e = lane >> 3, k = lane & 7;
     const int kk = k + (k >= 4);                             // 3x3 neighbourhood, row-major, centre skipped (:533-534)
     const int ox = kk % 3 - 1, oy = kk / 3 - 1;
-    int wcur = 0;                                            // g_wl[wave][wcur] is this sweep's worklist, [wcur ^ 1] the next one's
     int wl_cnt = 0;                                          // entries of this sweep's worklist (sweep >= 2)
-    bool filter = true;                                      // false once the list outgrew the worklists
+    bool filter = true;                                      // false once the list outgrew the worklist
     // Re-sweeps: an entry whose remaining candidates all failed by more than the sum vector has turned since cannot
     // accept anything now either (membership and bans only grow); it is carried over to the next worklist without
     // touching its neighbourhood.  meta[entry] = (unit sum vector its candidates were compared with, sine of the
@@ -524,12 +541,15 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         // (entries past n: harmless garbage, masked by valid.)  The LDS part of the list is read unconditionally and the HBM part
         // in a block of its own that also waits for it: a load whose register is still pending at the join would make the
         // compiler put an s_waitcnt vmcnt(0) in front of every batch, and that waits for the stamp stores of the batch before.
-        uint32_t pk = G_LST(wave)[direct ? eidx : min(eidx, LCAP - 1)];
-        if (!direct && ballot64(valid & (eidx >= LCAP))) {
-            uint32_t t = pk;
-            if (valid & (eidx >= LCAP)) t = c.spill[eidx - LCAP];
-            asm volatile("; spilled list entry %0" :: "v"(t));
-            pk = t;
+        uint32_t pk = G_LST(wave)[eidx & LMASK];
+        if (!direct) {                                       // entries that have left the ring (wave-uniform: only a list longer than the ring has any)
+            const int lo = wt ? n - LCAP : 0;
+            if (ballot64(valid & (eidx < lo))) {
+                uint32_t t = pk;
+                if (valid & (eidx < lo)) t = spill[(uint32_t)eidx];
+                asm volatile("; spilled list entry %0" :: "v"(t));
+                pk = t;
+            }
         }
         const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
         bool inb = valid & ((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h);   // :536 (plain &: no short-circuit branches)
@@ -592,8 +612,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         const int idx = n + mbcnt(P);
                         G_TW(wave)[cell] = word_r | 2u;                           // :549
                         stamp[(uint32_t)q] = id;
-                        if (n + 64 <= LCAP) G_LST(wave)[idx] = pack_xy(nx, ny);   // :551-556
-                        else lset(c, idx, pack_xy(nx, ny));
+                        G_LST(wave)[idx & LMASK] = pack_xy(nx, ny);               // :551-556
+                        if (wt) spill[(uint32_t)idx] = pack_xy(nx, ny);
                     }
                     float ps = 0.0f, pc2 = 0.0f;
                     unsigned long long todo = P;
@@ -651,6 +671,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     const float cl = rlf(cf, l), sl = rlf(sf, l);
                     const int ql = __builtin_amdgcn_readlane(q, l);
                     if (decided < 0) {
+                        g_ctx[wave].llo = wt ? max(n - LCAP, 0) : 0;              // (all lanes, same value: what exact_sums()'s reads go by)
                         exact_sums(c.wave, n);
                         const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
                         DSTAT(ST_EXACT, 1);
@@ -660,7 +681,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         if (lane == l) {
                             G_TW(wave)[cell] = word_r | 2u;                       // :549
                             stamp[(uint32_t)q] = id;
-                            lset(c, n, pack_xy(nx, ny));                          // :551-556
+                            G_LST(wave)[n & LMASK] = pack_xy(nx, ny);             // :551-556
+                            if (wt) spill[(uint32_t)n] = pack_xy(nx, ny);
                         }
                         Ce += (double)cl; Se += (double)sl;
                         n++;
@@ -694,8 +716,9 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                 }
                 const unsigned long long hm = ballot64(has & (k == 0));
                 const int add = __builtin_popcountll(hm);
-                const bool room = nxt_cnt + add <= LCAP && n <= 65535;
-                G_WL(wave, wcur ^ 1)[(room & has & (k == 0)) ? nxt_cnt + mbcnt(hm) : LCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
+                const bool room = nxt_cnt + add <= WCAP && n <= 65535;
+                // (in place: the next worklist never passes the read cursor -- every entry written was read before, in this batch or earlier)
+                G_WL(wave)[(room & has & (k == 0)) ? nxt_cnt + mbcnt(hm) : WCAP] = (uint16_t)eidx;   // (no branch: dummy slot)
                 filter = filter && room;
                 nxt_cnt += room ? add : 0;
             }
@@ -709,7 +732,12 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     // produce at will) -- and then runs the whole loop as divergent code on the vector unit.  Saying it again at the top of
     // every iteration costs nothing where the analysis already knows, and keeps the control flow scalar where it does not.
 #define GROW_ESTIMATE()                                                                                                   \
-    n = uni(n); nxt_cnt = uni(nxt_cnt); filter = uni((int)filter) != 0;                                                 \
+    n = uni(n); nxt_cnt = uni(nxt_cnt); filter = uni((int)filter) != 0; wt = uni((int)wt) != 0;                          \
+    if (!wt && n + 64 > LCAP) {             /* the batch to come may wrap the ring: from here on the list is in HBM as well */ \
+        for (int k2 = lane; k2 < n; k2 += 64) spill[(uint32_t)k2] = G_LST(wave)[k2];                                      \
+        wg_fence();                                                                                                       \
+        wt = true;                                                                                                        \
+    }                                                                                                                     \
     const float Cf = (float)Ce, Sf = (float)Se;                      /* the estimate of this batch (same in every lane) */ \
     const float V2 = __builtin_fmaf(Cf, Cf, Sf * Sf);                                                                     \
     const float rV = __builtin_amdgcn_rsqf(fmaxf(V2, 1e-12f)) * 1.000001f;   /* >= 1 / |V| */                             \
@@ -737,7 +765,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         flt_base = wi;
                         bool nd = false;
                         if (wi + lane < wl_cnt) {
-                            const int ei = (int)G_WL(wave, wcur)[wi + lane];
+                            const int ei = (int)G_WL(wave)[wi + lane];
                             nd = true;
                             if (ei < mcap) {
                                 const nf4 mt = meta[(uint32_t)ei];
@@ -755,8 +783,9 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     const int nskip = rest ? min(__builtin_ctzll(rest), nval) : nval;
                     if (nskip > 0) {                         // a run of entries that cannot accept anything: carry them over
                         // (lane-dependent branches stay in the MIDDLE of wave-uniform blocks, see STAT)
-                        const bool room = nxt_cnt + nskip <= LCAP;
-                        G_WL(wave, wcur ^ 1)[room && lane < nskip ? nxt_cnt + lane : LCAP] = G_WL(wave, wcur)[min(wi + lane, LCAP - 1)];   // (no branch: dummy slot)
+                        const bool room = nxt_cnt + nskip <= WCAP;
+                        // (in place: all 64 lanes read before any of them writes, and nxt_cnt <= wi)
+                        G_WL(wave)[room && lane < nskip ? nxt_cnt + lane : WCAP] = G_WL(wave)[min(wi + lane, WCAP - 1)];   // (no branch: dummy slot)
                         filter = filter && room;
                         nxt_cnt += room ? nskip : 0;
                         wi += nskip;
@@ -766,7 +795,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     const unsigned long long inv = ~rest;
                     cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
                 }
-                const int eidx = e < cnt ? (int)G_WL(wave, wcur)[wi + e] : 0;
+                const int eidx = e < cnt ? (int)G_WL(wave)[wi + e] : 0;
                 wi += batch(cnt, eidx, false, Cf, Sf, rV, Vn, nrat);
             }
         }
@@ -775,16 +804,16 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
             i = uni(i);
             if (i >= n) break;
             const int cnt = min(8, n - i);
-            i += batch(cnt, i + e, i + 8 <= LCAP, Cf, Sf, rV, Vn, nrat);
+            i += batch(cnt, i + e, n - i <= LCAP, Cf, Sf, rV, Vn, nrat);   // (direct: entries i .. n - 1 are all in the ring)
         }
-        wcur ^= 1;
         wl_cnt = nxt_cnt;
         sweep++;
         flt_valid = false;
         if (n != ex && n > 8) wg_fence();                    // meta[] written in this sweep is read in the next
     } while (n != ex);
 #undef GROW_ESTIMATE
-    if (lane == 0) g_ws[wave].gnum = n;
+    if (lane == 0) { g_ws[wave].gnum = n; g_ctx[wave].llo = wt ? max(n - LCAP, 0) : 0; }
+    if (wt) wg_fence();                                      // the written-through part is read back by the stages that follow
     STAT(ST_GROW, 1);
     STAT(ST_GROWN, n);
     DSTAT(ST_TGROW, NOW() - t0);
@@ -908,6 +937,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
     if (den > denThre) return num;                                                 // :760
     // keep the grow-order list for the marking loops before it gets reordered
     for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
+    invalidate_tiles(c);                                                           // (the scratch below takes the tile cache's place)
     if (lane == 0) { g_ws[c.wave].has_copy = 1; g_ws[c.wave].dirty = 0; }
     wg_fence();
     const Rec rec = g_ws[c.wave].rec;
@@ -917,7 +947,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
     bool removed_any = false;
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
     unsigned long long* const msk = reinterpret_cast<unsigned long long*>(g_acc[wave]);   // keep-masks of up to 128 chunks of 64 entries
-    uint32_t* const mv = reinterpret_cast<uint32_t*>(G_WL(wave, 0));                       // up to LCAP moved entries (the worklists are free here)
+    uint32_t* const mv = reinterpret_cast<uint32_t*>(G_WL(wave));                          // up to kMvCap moved entries: the worklist and the tile cache behind it
     while (den < denThre) {                                                        // :775
         rad *= 0.75;
         STAT(ST_RRRPASS, 1);
@@ -941,7 +971,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                 msk[ci] = nearm;                           // (all lanes, same value)
                 K += __builtin_popcountll(nearm);
             }
-            if (min(K, num - K) > LCAP) parallel = false;  // more moves than mv[] holds
+            if (min(K, num - K) > kMvCap) parallel = false;  // more moves than mv[] holds
         }
         if (parallel) {
             if (K != num) {
@@ -951,7 +981,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                     const bool is = (((msk[ci] >> lane) & 1ull) != 0ull) & (idx >= K);
                     const unsigned long long mm = ballot64(is);
                     const int above = __builtin_popcountll((mm >> lane) >> 1);
-                    mv[is ? nm + above : LCAP] = is ? lget(c, idx) : 0u;           // (no branch: dummy slot; the worklists have 2 spare entries each = 2 words)
+                    mv[is ? nm + above : kMvCap] = is ? lget(c, idx) : 0u;         // (no branch: dummy slot)
                     nm += __builtin_popcountll(mm);
                 }
                 int nh = 0;                                // far points of the slots < K, lowest slot first
@@ -1065,7 +1095,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
     int all = 0, ali = 0;
     // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
-    int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave, 0));
+    int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave));
     int* const s_lo = s_incl + 64;
     int* const s_x = s_incl + 128;
     for (int cb = 0; cb < xlen; cb += 64) {
@@ -1320,6 +1350,7 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
         bool done = false;
         for (int pass = 0; pass < 2 && !done; pass++) {
             num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
+            c.llo = g_ctx[wave].llo;                                                   // (which part of the new list is in the ring)
             if (pass == 0 && spec && num <= gcap) {                // keep the first list for the validation at the cursor
                 for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
                 n1 = num;

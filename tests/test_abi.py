@@ -283,3 +283,12 @@ def test_region_kernel_keeps_its_registers_and_stays_out_of_scratch(tmp_path):
     occ = int(re.search(r"; Occupancy: (\d+)", kern).group(1))
     assert vgprs <= 256 and occ >= 2, (vgprs, occ)
     assert scratch <= 320, scratch
+    # the 4-wave build (throughput mode) is compiled for THREE workgroups per CU: 3 waves per SIMD (<= 168 registers), LDS <= 160 KB / 3
+    out4 = str(tmp_path / "k_region_w4.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DLSD_REGION_NW=4",
+                    "-DLSD_REGION_WAVES_PER_SIMD=3", "-S", "--cuda-device-only", "-o", out4, src], check=True, capture_output=True)
+    text = open(out4).read()
+    kern = text[text.index("; Kernel info:"):]
+    assert int(re.search(r"; NumVgprs: (\d+)", kern).group(1)) <= 168 and int(re.search(r"; Occupancy: (\d+)", kern).group(1)) >= 3
+    assert int(re.search(r"; LDSByteSize: (\d+)", kern).group(1)) * 3 <= 160 * 1024
+    assert int(re.search(r"; ScratchSize: (\d+)", kern).group(1)) <= 640

@@ -401,15 +401,16 @@ def test_whole_bench_batch_matches_oracle(maps, lsdmod, ctx, oracle):
 
 
 def test_timed_configuration_of_the_bench_matches_oracle(maps, lsdmod, oracle):
-    """The configuration bench.py's `value` is timed on, exactly: the 512 x 2048x2048 batch, FOUR contexts / streams / output sets
-    in flight (bench.py --pipeline 4), the 4-wavefront region stage (lsd_set_region_waves 4), help across workgroups off
-    (lsd_set_region_help 0), no LSD_FLAG_WRITEBACK_MAP (the four steps share one resident input), three rounds of four steps.
+    """The configuration bench.py's `value` is timed on, exactly: the 512 x 2048x2048 batch, EIGHT contexts / streams / output sets
+    in flight (bench.py --pipeline 8, GPU_MAX_HW_QUEUES=8 from conftest), the 4-wavefront region stage (lsd_set_region_waves 4: three
+    workgroups per CU), help across workgroups off (lsd_set_region_help 0), no LSD_FLAG_WRITEBACK_MAP (the steps share one resident
+    input), three rounds of eight steps.
     Context 0 of the last round is compared with the oracle image by image (counts, line records, lineIm); every other
     (round, context) result must equal it byte for byte -- counts, the valid line records and lineIm."""
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    n, size, depth, cap = 512, 2048, 4, 1024
+    n, size, depth, cap = 512, 2048, 8, 1024
     host = bench.make_batch(maps, n, size)
     d = torch.from_numpy(host).cuda()
     ctxs = [lsdmod.Context(0) for _ in range(depth)]
@@ -419,14 +420,14 @@ def test_timed_configuration_of_the_bench_matches_oracle(maps, lsdmod, oracle):
     keep = None
     try:
         for c in ctxs:
-            c.reserve(n, size, size)
             c.set_region_help(0)
             c.set_region_waves(4)
+            c.reserve(n, size, size)
         for rnd in range(3):
             for o in outs:
                 for t in o: t.fill_(7)                     # (stale results of the round before cannot pass for new ones)
             torch.cuda.synchronize()
-            for c, o, st in zip(ctxs, outs, streams):      # the four steps are enqueued back to back, as bench.py's timed loop does
+            for c, o, st in zip(ctxs, outs, streams):      # the steps are enqueued back to back, as bench.py's timed loop does
                 c.enqueue_device(d.data_ptr(), n, size, size, o[0].data_ptr(), cap, o[1].data_ptr(), d_line_ims=o[2].data_ptr(), stream=st.cuda_stream)
             torch.cuda.synchronize()
             assert torch.equal(d.cpu(), torch.from_numpy(host))                      # no write-back: the shared input is untouched

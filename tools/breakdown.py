@@ -10,13 +10,24 @@ lsd = importlib.import_module("linesegmentdetector-slam_amd")
 maps = bench.load_maps()
 waves = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n, size = int(sys.argv[2]) if len(sys.argv) > 2 else 512, 2048
-ctx = lsd.Context(0)
-ctx.set_region_waves(waves); ctx.set_region_help(0)
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # steps in flight (the loaded regime: GPU_MAX_HW_QUEUES=8 for more than 4)
+ctxs = [lsd.Context(0) for _ in range(depth)]
+ctx = ctxs[0]
 d = torch.from_numpy(bench.make_batch(maps, n, size)).cuda()
-lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
-s = torch.cuda.current_stream().cuda_stream
+outs, streams = [], []
+for c_ in ctxs:
+    c_.set_region_waves(waves); c_.set_region_help(0); c_.reserve(n, size, size)
+    outs.append((torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")))
+    streams.append(torch.cuda.Stream())
+import time
 for rep in range(2):
-    ctx.enqueue_device(d.data_ptr(), n, size, size, lines.data_ptr(), 1024, counts.data_ptr(), stream=s); torch.cuda.synchronize()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for it in range(3 if depth > 1 else 1):
+        for c_, o, st_ in zip(ctxs, outs, streams):
+            c_.enqueue_device(d.data_ptr(), n, size, size, o[0].data_ptr(), 1024, o[1].data_ptr(), stream=st_.cuda_stream)
+    torch.cuda.synchronize()
+    print("depth %d: %.1f ms per step" % (depth, (time.perf_counter() - t0) * 1e3 / (depth * (3 if depth > 1 else 1))))
+ctx = ctxs[depth // 2]                                         # a step from the middle of the pack
 print({k: round(v, 2) for k, v in ctx.timings().items()})
 wh = lsd.scaled_size(size, size)
 st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
