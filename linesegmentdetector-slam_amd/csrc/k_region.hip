@@ -1509,10 +1509,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     __shared__ int s_nhelp, s_xout, s_xlock, s_xreg, s_xpub, s_idlecnt, s_xc_last, s_xt_last, s_workbound;
     __shared__ int s_xk[kXReq];
 
-    const size_t img = b.order[blockIdx.x];               // heaviest images first (k_order)
-    uint32_t* const xr = b.xq ? b.xq + img * (size_t)kXStride : nullptr;                    // this image's record of the help protocol
-    uint32_t* const xhdr = b.xq ? b.xq + (size_t)gridDim.x * kXStride : nullptr;             // ... and the launch's
-    if (threadIdx.x == 0 && xhdr) atomicAdd(&xhdr[0], 1u);
+    // The last b.npool workgroups of the launch own no image: they are HELPERS from the start (the host adds them when the images
+    // leave workgroup slots of the device free, see "Help from other workgroups" below), with a workspace slot of their own.
+    const int nimg = (int)gridDim.x - b.npool;
+    const bool pool = (int)blockIdx.x >= nimg;
+    const size_t img = pool ? (size_t)blockIdx.x : (size_t)b.order[blockIdx.x];           // heaviest images first (k_order); pool: its workspace slot
+    uint32_t* const xr = (b.xq && !pool) ? b.xq + img * (size_t)kXStride : nullptr;        // this image's record of the help protocol
+    uint32_t* const xhdr = b.xq ? b.xq + (size_t)nimg * kXStride : nullptr;                 // ... and the launch's
+    if (threadIdx.x == 0 && xhdr && !pool) atomicAdd(&xhdr[0], 1u);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = g.w, h = g.h;
     const size_t npx = (size_t)g.npx;
@@ -1545,7 +1549,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
     uint32_t* seedpos = b.seedpos + img * npx;
-    const int nb = b.nb[img];
+    const int nb = pool ? 0 : b.nb[img];
     double* recs = b.recs + img * (size_t)b.max_lines * 12;
     double* recs_scaled = b.recs_scaled + img * (size_t)b.max_lines * 4;
     SeedRec* trace = b.seeds ? reinterpret_cast<SeedRec*>(b.seeds) + img * npx : nullptr;
@@ -1570,6 +1574,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         }
         if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(cnt, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
         wg_fence();
+        if (xr) agent_release();                           // helpers on other XCDs read seedpos[] as soon as a request names a seed
     }
     __syncthreads();
     const int nseeds = s_nseeds;
@@ -1912,7 +1917,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             const int tn = (int)__builtin_amdgcn_s_memtime(), dt = tn - s_xt_last;
             if (dt > 200000) {
                 const int ic = lds_ld(&s_idlecnt);
-                s_workbound = (long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 100 < (long long)dt * NW * b.tun_wb ? 1 : 0;   // idle < tun_wb %
+                // ... and only an image that has been running for a while asks at all (tun_gate, in 1024-clock units): the typical image is
+                // through before help could pay for the traffic it causes, the heavy ones are the ones that run long
+                s_workbound = ((long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 100 < (long long)dt * NW * b.tun_wb &&
+                               (long long)__builtin_amdgcn_s_memtime() - t_begin > (long long)b.tun_gate * 1024) ? 1 : 0;   // idle < tun_wb %
                 s_xc_last = ic; s_xt_last = tn;
             }
             const int nbg = s_workbound ? max(lds_ld(&s_nbig), 0) : 0;
@@ -2394,11 +2402,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     }
 
     // ---- this image is finished (every seed committed, or given up): results out ----
-    if (wave == 0 && lane == 0) {
+    if (wave == 0 && lane == 0 && !pool) {
         b.counts[img] = lds_ld(&s_abort) ? -1 : s_lines;
         if (b.nseed) b.nseed[img] = s_ntrace;
     }
-    if (b.stats) {
+    if (b.stats && !pool) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
         if (lane == 0 && wave == 0 && !lds_ld(&s_abort)) { b.stats[img * kStatWords + 45] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15); b.stats[img * kStatWords + 46] = rt_begin; b.stats[img * kStatWords + 47] = (long long)__builtin_amdgcn_s_memrealtime(); }   // (developer record: when the image ran)
         if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth)); }
@@ -2408,15 +2416,15 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         }
         g_stat[c.wave][sslot(ST_XHELP)] = 0ull;
     }
-    if (!xr) return;
-    if (wave == 0) {
+    if (!b.xq) return;
+    if (wave == 0 && !pool) {
         agent_release();
         if (lane == 0) { st_l2(&xr[2], 1u); atomicAdd(&xhdr[1], 1u); }
     }
     // While workgroups still wait for a CU this one should make room -- unless an image is so far behind with its evaluations
     // that a few wavefronts are better spent there (EARLY helpers: at most tun_early workgroups' worth at a time, only for images
     // with two backlogged seeds per wave of their own, and gone as soon as there is nothing of that kind)
-    bool early = ld_l2(&xhdr[0]) < gridDim.x;
+    bool early = !pool && ld_l2(&xhdr[0]) < (uint32_t)nimg;
     if (early) {
         if (b.tun_early <= 0) return;
         int ok = 0;
@@ -2436,12 +2444,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         int k = -1, slot = 0;
         if (hx < 0) {
             // ---- not attached: the image with the largest backlog per wave already working on it ----
-            if (ld_l2(&xhdr[1]) >= gridDim.x) break;   // every image is finished
-            if (early && ld_l2(&xhdr[0]) >= gridDim.x) {   // every workgroup has its CU by now
+            if (ld_l2(&xhdr[1]) >= (uint32_t)nimg) break;   // every image is finished
+            if (early && ld_l2(&xhdr[0]) >= (uint32_t)nimg) {   // every workgroup has its CU by now
                 early = false;
                 if (lane == 0) atomicSub(&xhdr[3], 1u);
             }
-            const int wt = min(min((int)ld_l2(&xhdr[2]), (int)gridDim.x), 4096);
+            const int wt = min(min((int)ld_l2(&xhdr[2]), nimg), 4096);
             uint32_t best = 0u;
             for (int base = 0; base < wt; base += 64) {
                 const int i = base + lane;
@@ -2555,14 +2563,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         continue;
     }
     // (a helper's count of evaluations done for others goes to its own image's record)
-    if (b.stats && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords) + ST_XHELP, g_stat[c.wave][sslot(ST_XHELP)]);
+    if (b.stats && lane == 0 && !pool) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords) + ST_XHELP, g_stat[c.wave][sslot(ST_XHELP)]);
 }
 
 }  // namespace RVAR
 
 #if LSD_REGION_NW == 8
 void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
-    hipLaunchKernelGGL(w8::k_region, dim3(n), dim3(64 * w8::NW), 0, s, g, b, id_base);
+    hipLaunchKernelGGL(w8::k_region, dim3(n + b.npool), dim3(64 * w8::NW), 0, s, g, b, id_base);
 }
 // workspace is sized for the wider variant
 int region_slots() { return w8::NS; }
@@ -2570,7 +2578,7 @@ int region_waves() { return w8::NW; }
 int region_ring() { return w8::RW; }
 #else
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
-    hipLaunchKernelGGL(w4::k_region, dim3(n), dim3(64 * w4::NW), 0, s, g, b, id_base);
+    hipLaunchKernelGGL(w4::k_region, dim3(n + b.npool), dim3(64 * w4::NW), 0, s, g, b, id_base);
 }
 #endif
 

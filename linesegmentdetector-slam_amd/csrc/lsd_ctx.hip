@@ -24,6 +24,8 @@ struct lsd_ctx {
     int tun_soft = 0, tun_claim = 0, tun_feed = 3, tun_big = 0;   // region-stage schedule (0: default), see k_region.hip
     int tun_help = -1;                                             // helper wavefronts per image (-1: default, 0: none)
     // developer experiments (environment variables read once, when the context is created; DESIGN_NOTES.md says what each was for)
+    int tun_gate = 12000;                                          // an image asks for help once it has run for this long (x 1024 clocks: ~5 ms)
+    int pool_max_images = 4;                                       // calls with at most this many images get a pool of helper workgroups (LSD_REGION_POOL)
     int tun_early = 0, tun_wb = 10, tun_up = 32, tun_down = 96, tun_requeue = 1, tun_xpoll = 20000, tun_linger = 1000000, tun_stop = 0;
     uint32_t* xq = nullptr;
     int region_waves_mode = 0;         // 0: choose per batch; 4 / 8: force that region-stage variant (lsd_set_region_waves)
@@ -221,8 +223,25 @@ static int waves_for(const lsd_ctx* c, int n) {
     return 4;
 }
 
+// Workgroups that own no image and help from the start (k_region.hip): as many as the images leave workgroup slots of the device
+// free -- one 8-wave workgroup per CU, three 4-wave ones -- and the images' helper wavefronts (tun_help each) can use.
+static int pool_for(const lsd_ctx* c, int n) {
+    const int help = c->tun_help >= 0 ? c->tun_help : 24;
+    // Measured (tools/single_step_probe.py): the heaviest bench image alone 77.5 -> 30 ms, typical single images unchanged (they never
+    // ask: tun_gate); a 64-image shard 49 -> 55 ms and the 512-image batch on 4 waves 87 -> 115 ms -- helpers that are there from the
+    // start serve many images that merely look busy, and every remote evaluation costs its owner an export, a poll and a validation
+    // out of HBM.  So the pool exists for calls with a handful of images (the reference's usage: one map per call); batches get their
+    // helpers from the workgroups that finish first, as before.
+    if (help <= 0 || c->trace || n > c->pool_max_images) return 0;
+    const int nw = waves_for(c, n);
+    const long long free_slots = (long long)(nw == 8 ? 1 : 3) * c->num_cus - n;
+    const long long want = ((long long)n * help + nw - 1) / nw;
+    const long long p = free_slots < want ? free_slots : want;
+    return p > 0 ? (int)p : 0;
+}
+
 static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
-    const size_t need_ws = n * (size_t)waves_for(c, (int)n);       // per-wave arrays: wave slots of the whole batch
+    const size_t need_ws = (n + (size_t)pool_for(c, (int)n)) * (size_t)waves_for(c, (int)n);   // per-wave arrays: wave slots of the images and of the helper pool
     const bool grow_main = n > c->cap_n || npx > c->cap_npx || gpx > c->cap_gpx || need_ws > c->cap_ws;
     if (grow_main) {
         const size_t nn = n > c->cap_n ? n : c->cap_n, pp = npx > c->cap_npx ? npx : c->cap_npx;
@@ -356,6 +375,8 @@ int lsd_create(lsd_ctx** out, int device) {
         env_int("LSD_REGION_HELP", -1, 4096, &c->tun_help);         // helper wavefronts per image (as lsd_set_region_help)
         env_int("LSD_REGION_EARLY", 0, 4096, &c->tun_early);        // helpers before every workgroup has its CU (measured: a loss)
         env_int("LSD_REGION_WB", 0, 100, &c->tun_wb);               // idle share (%) below which an image asks for help
+        env_int("LSD_REGION_GATE", 0, 1 << 22, &c->tun_gate);       // ... once it has been running for this long (x 1024 clocks)
+        env_int("LSD_REGION_POOL", 0, 1 << 20, &c->pool_max_images); // calls with at most this many images get helper-only workgroups
         env_int("LSD_REGION_UP", 0, 1 << 16, &c->tun_up);           // steps of the adaptive look-ahead
         env_int("LSD_REGION_DOWN", 0, 1 << 16, &c->tun_down);
         env_int("LSD_REGION_REQUEUE", 0, 1, &c->tun_requeue);       // 0: invalidated results are found at the cursor only
@@ -459,9 +480,10 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
         b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
-        b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
+        b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_gate = c->tun_gate; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
         b.tun_xpoll = c->tun_xpoll; b.tun_linger = c->tun_linger; b.tun_stop = c->tun_stop;
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
+        b.npool = b.xq ? pool_for(c, n) : 0;
     }
     b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;

@@ -75,8 +75,10 @@ struct Buffers {
     int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
     uint32_t* xq;          // n x kXStride + kXHdr + n : control block of the help across workgroups (see above), null: no help
     int tun_help;          // helper wavefronts an image may have attached
+    int npool;             // workgroups at the end of the region stage's launch that own no image and help from the start (workspace slots n .. n + npool - 1)
     int tun_early;         // workgroups that may help while others still wait for a CU
     int tun_wb;            // an image asks for help while its waves idle less than this share of the time (percent)
+    int tun_gate;          // ... and once it has been running for this long (1024-clock units)
     int tun_up, tun_down;  // steps of the adaptive look-ahead (seeds): up when a wave finds nothing to do, down on a redo / discard
     int tun_requeue;       // results invalidated by a line are queued for another evaluation when the line is accepted (1) or found at the cursor (0)
     int tun_xpoll;         // shader clocks between two looks of a wave at the help protocol
