@@ -191,8 +191,9 @@ def cpu_baseline(size, first, sample=24, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=128, help="timed steps (the timed region ends with the drain of the steps in flight -- ~one step latency, "
+                    "0.3 s at depth 8 -- so a short run under-reports the rate a service sees; 128 steps take ~6 s)")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)
@@ -494,7 +495,7 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
         # the same split in THROUGHPUT mode: what an N-GPU job sees when every rank keeps `depth` steps in flight on its shard
         # (contexts ctxs[], 4-wave region stage, help off -- the configuration of this line's `value`), ms per sharded step
         if len(ctxs) > 1:
-            def run_shard_pipelined(lo, hi, steps=8):
+            def run_shard_pipelined(lo, hi, steps=32):
                 for c_ in ctxs:
                     c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
                 def go(i):

@@ -905,6 +905,31 @@ def test_feature_scan_batch_matches_oracle(lsdmod, ctx, oracle):
     assert np.array_equal(one["scanImPoint"], got[5]["scanImPoint"]) and one["linesInfo"].tobytes() == got[5]["linesInfo"].tobytes()
 
 
+def test_helper_pool_on_single_images_is_repeatable(maps, lsdmod, oracle):
+    """A call with a handful of images gets helper-only workgroups from the start of the region stage (lsd_ctx.hip: pool_for): the
+    heaviest bench image and two fixtures, each alone and 12 times over, must give the oracle's answer every time -- byte for byte the
+    answer of a context with the help switched off -- and the heavy image must actually have been helped."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cases = [("bench187", bench.make_image(maps, 187, 2048)), ("f4key", maps["f4key"]), ("f3key", maps["f3key"])]
+    on, off = lsdmod.Context(0), lsdmod.Context(0)
+    off.set_region_help(0)
+    try:
+        for name, img in cases:
+            ref = oracle.lsd(img.copy())
+            l0, im0 = off.run(img.copy())
+            assert_lines_close(l0, ref["lines"]); assert np.array_equal(im0, ref["lineIm"])
+            helped = 0
+            for rep in range(12):
+                l1, im1 = on.run(img.copy())
+                assert l1.tobytes() == l0.tobytes() and np.array_equal(im1, im0), (name, rep)
+                helped += on.fetch(0, lsdmod.DBG_STATS, lsdmod.scaled_size(img.shape[1], img.shape[0]))["help_exports"]
+            if name == "bench187":
+                assert helped > 1000, helped
+    finally:
+        on.close(); off.close()
+
+
 def test_feature_scan_more_lines_than_the_reference_array_holds(lsdmod, ctx, oracle):
     """A 1024-reading zigzag whose every reading becomes a split point gives ~1000 chords; the reference's array holds 360 (:39).
     n_lines reports them all, the first 360 records are stored and equal the oracle's, the host entry point says LSD_ERR_CAPACITY."""

@@ -7,6 +7,7 @@ cd $R
 python -m pytest tests -m gpu -x -q > $O/${tag}_gputests.log 2>&1; echo "gpu tests rc $?"; tail -3 $O/${tag}_gputests.log
 [ $N -gt 0 ] && { python3 tools/campaign.py $N > $O/${tag}_campaign_$N.log 2>&1; tail -2 $O/${tag}_campaign_$N.log; }
 [ $NB -gt 0 ] && { CAMPAIGN_BIG=1 python3 tools/campaign.py $NB > $O/${tag}_campaign_big$NB.log 2>&1; tail -2 $O/${tag}_campaign_big$NB.log; }
+python3 tools/campaign_batch.py 60 48 > $O/${tag}_campaign_batch.log 2>&1; tail -2 $O/${tag}_campaign_batch.log
 tools/profile_round.sh $tag
 tools/pmc_sq.sh ${tag}_w8_187 8 187
 tools/pmc_sq.sh ${tag}_w4_187 4 187
