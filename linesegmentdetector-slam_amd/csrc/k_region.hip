@@ -2440,6 +2440,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     int hx = -1, hj = 0, hidle = 0, hscan = 0;              // image this wave helps (-1: none), request it is answering, looks without work / for an image
     uint32_t* hrec = nullptr;                               // that image's record of the help protocol
     const uint32_t* cur_seedpos = seedpos;
+    // the work counters of an evaluation done for another image (grows, grown pixels, NFA and RegionRadiusReducer calls: slots 0..6)
+    // go to THAT image's record, as if its own waves had done it
+    unsigned long long hprev = lane < 7 ? g_stat[c.wave][lane] : 0ull;
     while (true) {
         int k = -1, slot = 0;
         if (hx < 0) {
@@ -2527,6 +2530,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             g_ws[wave].cache_epoch = epoch_snap;
         }
         eval_seed(c.wave, pp, 1, slot);
+        if (b.stats && lane < 7) {
+            const unsigned long long v = g_stat[c.wave][lane];
+            if (v != hprev) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + (size_t)hx * kStatWords) + lane, v - hprev);
+            hprev = v;
+        }
         const EvalOut& eo = g_eo[wave];
         const bool skip = eo.skip != 0;
         const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;
