@@ -98,7 +98,7 @@ struct WState {
     uint32_t cur_id;     // stamp of the current grow (id_base + running number)
     int gnum;            // size of the last grow (grow order)
     int has_copy;        // gcopy holds the grow-order list (RegionRadiusReducer reordered lst)
-    int dirty;           // stamps stored to HBM since the last fence
+    int tm_pending;      // member masks of evicted tiles stored to HBM since the last fence
     int cache_epoch;     // accept epoch the tile cache was (re)started at; -1: empty
     int members_cached;  // the cache may hold member bits of the last grow
     int ex_upto;         // exact angle sums of the last grow, caught up lazily in list order (myLSD.cpp:545-546)
@@ -113,7 +113,7 @@ struct RCtx {
     uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
     uint32_t* epochmap;
     uint32_t* tep;       // per 8x8-pixel tile: epoch + 1 of the latest accepted line with a pixel in it (0: none)
-    uint32_t* stamp;     // this wave's curMap stamps
+    uint32_t* tmask;     // this wave's member masks of evicted tiles: 4 words per 8x8 tile (grow id, -, 64 member bits)
     uint32_t* spill;
     uint32_t* gcopy;
     float4* meta;        // HBM [mcap]: (unit sum vector, sin of the smallest slack) of the last full test of a list entry, see grow()
@@ -121,7 +121,7 @@ struct RCtx {
     const double2* sc;   // (sin, cos)(deg)
     int tilesX;
     uint32_t id_base;
-    uint32_t id_budget;  // grows a wave may stamp before it has to clear its stamps (< 2^20: the next run's ids start there)
+    uint32_t id_budget;  // grows a wave may number before it has to clear its member masks (< 2^20: the next run's ids start there)
     double logNT;
     const double* lgamma;
     const double* ptab;
@@ -295,10 +295,12 @@ __device__ __forceinline__ double angle_diff(double a, double b) {  // myLSD.cpp
 // LDS tile cache: 8x8-pixel tiles of packed pixel words, NT slots, slot = (tx + 5 ty) mod NT (rows, columns
 // and diagonals of tiles spread over all slots).  RegionGrower reads its 3x3 neighbourhoods from here, so a
 // batch costs LDS latency instead of dependent HBM round trips.  A cached word is the pixel's pw with the code
-// replaced by two flags: bit 0 = banned (code 1 or 3), bit 1 = member of the current grow (curMap).  Accepted
-// pixels are flagged in the LDS copy AND stamped in HBM (write-through, never waited for, re-read when a tile
-// comes back after an eviction).  The cache survives from seed to seed while no line is accepted in the image
-// (a tile fetched before an accept could miss a ban that the snapshot of a later seed no longer flags).
+// replaced by two flags: bit 0 = banned (code 1 or 3), bit 1 = member of the current grow (curMap).  The member
+// flags live in the cache; a tile that is evicted with members leaves them in HBM as a 64-bit mask tagged with the
+// grow's id (`tmask`, 16 bytes per tile and wave), and takes them back when it returns.  (Until round 4 every accepted
+// pixel was stamped in a 4-byte-per-pixel map instead: a scattered store per pixel and a fence in front of most tile
+// fetches.)  The cache survives from seed to seed while no line is accepted in the image (a tile fetched before an
+// accept could miss a ban that the snapshot of a later seed no longer flags).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx + 5 * ty) & (NT - 1); }
 
@@ -306,6 +308,20 @@ __device__ __forceinline__ int tile_slot(int tx, int ty) { return (tx + 5 * ty) 
 // to the same slot (the caller retries with a smaller batch; a single 3x3 neighbourhood never conflicts).
 // A tile's tag is (tile row << 16 | tile column).
 __device__ __forceinline__ int tile_key(int tx, int ty) { return (ty << 16) | tx; }
+__device__ __forceinline__ uint32_t tm_index(const RCtx& c, int key) { return 4u * (uint32_t)((key >> 16) * c.tilesX + (key & 0xffff)); }
+// curMap of a pixel whose tile is NOT in the cache (the stages after RegionRadiusReducer, which empties the cache into tmask first):
+// read past the L1, the reducer clears bits with atomics
+__device__ __forceinline__ bool tm_member(const RCtx& c, int x, int y, uint32_t id) {
+    const uint32_t* t = c.tmask + tm_index(c, tile_key(x >> 3, y >> 3));
+    const int b = ((y & 7) << 3) | (x & 7);
+    return __hip_atomic_load(&t[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == id &&
+           ((__hip_atomic_load(&t[2 + (b >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (b & 31)) & 1u) != 0u;
+}
+__device__ __forceinline__ void tm_clear(const RCtx& c, int x, int y) {           // curMap(x, y) = 0
+    uint32_t* t = c.tmask + tm_index(c, tile_key(x >> 3, y >> 3));
+    const int b = ((y & 7) << 3) | (x & 7);
+    atomicAnd(&t[2 + (b >> 5)], ~(1u << (b & 31)));
+}
 __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, int py) {
     const int lane = c.lane, w = c.w, h = c.h, wave = c.wave;
     const int tx = px >> 3, ty = py >> 3;
@@ -324,10 +340,10 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
         }
     }
     [[maybe_unused]] const long long tt0 = NOW();
-    if (__builtin_amdgcn_readfirstlane(g_ws[wave].dirty)) { wg_fence(); g_ws[wave].dirty = 0; }   // earlier stamps must have landed before a tile is (re)read
+    if (__builtin_amdgcn_readfirstlane(g_ws[wave].tm_pending)) { wg_fence(); g_ws[wave].tm_pending = 0; }   // masks of tiles evicted earlier must have landed before one of them is read back
     const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_ws[wave].cur_id);
     AS1 const uint32_t* const pw = uglobal(c.pw);
-    AS1 const uint32_t* const stamp = uglobal(c.stamp);
+    AS1 uint32_t* const tm = uglobal(c.tmask);
     const int lx = lane & 7, ly = lane >> 3;
     while (todo) {
         // up to 4 missing tiles per round, all loads in flight together
@@ -344,23 +360,38 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
                 nt++;
             }
         }
-        uint32_t vw[4], vs[4];
+        // the tiles that make room leave their member flags in HBM (most have none: nothing is stored for them)
         #pragma unroll
         for (int j = 0; j < 4; j++) {
-            vw[j] = kPwStatic; vs[j] = 0u;                        // outside the image: banned
+            if (j < nt) {
+                const int old = __builtin_amdgcn_readfirstlane(g_ttag[wave][S[j]]);
+                const unsigned long long om = old != -1 ? ballot64((G_TW(wave)[S[j] * 64 + lane] & 2u) != 0u) : 0ull;
+                if (om) {
+                    if (lane == 0) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 rec = {id, 0u, (uint32_t)om, (uint32_t)(om >> 32)};
+                        *reinterpret_cast<AS1 u32x4*>(tm + tm_index(c, old)) = rec;
+                    }
+                    g_ws[wave].tm_pending = 1;                 // (all lanes, same value)
+                }
+            }
+        }
+        uint32_t vw[4], vi[4], vm[4];
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            vw[j] = kPwStatic; vi[j] = 0u; vm[j] = 0u;            // outside the image: banned
             if (j < nt) {
                 const int x = (T[j] & 0xffff) * 8 + lx, y = (T[j] >> 16) * 8 + ly;
-                if ((x < w) & (y < h)) {
-                    const uint32_t q = (uint32_t)(y * w + x);
-                    vw[j] = pw[q];
-                    vs[j] = stamp[q];
-                }
+                if ((x < w) & (y < h)) vw[j] = pw[(uint32_t)(y * w + x)];
+                AS1 const uint32_t* t = tm + tm_index(c, T[j]);
+                vi[j] = t[0]; vm[j] = t[2 + (lane >> 5)];          // (two addresses per tile for the whole wave)
             }
         }
         #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < nt) {
-                G_TW(wave)[S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (vs[j] == id ? 2u : 0u);
+                const uint32_t mem = (vi[j] == id) ? ((vm[j] >> (lane & 31)) & 1u) : 0u;
+                G_TW(wave)[S[j] * 64 + lane] = (vw[j] & ~3u) | (vw[j] & 1u) | (mem << 1);
                 g_ttag[wave][S[j]] = T[j];                 // (all lanes, same value)
             }
         }
@@ -372,6 +403,23 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
 __device__ __forceinline__ void invalidate_tiles(const RCtx& c) {
     if (c.lane < NT) g_ttag[c.wave][c.lane] = -1;
     g_ws[c.wave].members_cached = 0;
+}
+// Empties the cache into tmask: afterwards curMap of the current grow is in HBM in full (RegionRadiusReducer clears bits there, the
+// marking stages read them there).
+__device__ __forceinline__ void flush_tiles(const RCtx& c) {
+    const uint32_t id = g_ws[c.wave].cur_id;
+    for (int sl = 0; sl < NT; sl++) {
+        const int old = __builtin_amdgcn_readfirstlane(g_ttag[c.wave][sl]);
+        if (old == -1) continue;
+        const unsigned long long om = ballot64((G_TW(c.wave)[sl * 64 + c.lane] & 2u) != 0u);
+        if (om && c.lane == 0) {
+            uint32_t* t = c.tmask + tm_index(c, old);
+            t[0] = id; t[1] = 0u; t[2] = (uint32_t)om; t[3] = (uint32_t)(om >> 32);
+        }
+    }
+    invalidate_tiles(c);
+    wg_fence();
+    g_ws[c.wave].tm_pending = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,7 +502,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     const double regDeg0 = uni(regDeg0_), tol = uni(tol_);
     const int w = uni(c.w), h = uni(c.h), wave = uni(c.wave), mcap = uni(c.mcap);
     const int sx = uni(sx_), sy = uni(sy_);
-    AS1 uint32_t* const stamp = uglobal(c.stamp);
     AS1 nf4* const meta = (AS1 nf4*)uglobal(c.meta);
     c.w = w; c.h = h; c.wave = wave;                         // (what the helpers below read)
     [[maybe_unused]] const long long t0 = NOW();
@@ -473,7 +520,8 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     }
     uint32_t id = (uint32_t)uni((int)g_ws[wave].cur_id);
     if ((id - (uint32_t)uni((int)c.id_base)) >= (uint32_t)uni((int)c.id_budget)) {                      // the run's 2^20 stamp ids are used up: start over on clean stamps
-        for (size_t q = lane; q < (size_t)w * h; q += 64) stamp[q] = 0u;
+        const uint32_t tmw = 4u * (uint32_t)(c.tilesX * ((h + 7) >> 3));
+        for (uint32_t q = lane; q < tmw; q += 64) c.tmask[q] = 0u;
         wg_fence();
         id = c.id_base;
     }
@@ -496,8 +544,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         if (lane == 0) {
             G_LST(wave)[0] = pack_xy(sx, sy);
             G_TW(wave)[slot * 64 + ti] = sw | 2u;            // :520
-            stamp[sy * w + sx] = id;
-            g_ws[wave].dirty = 1;
         }
     }
     int n = 1;
@@ -611,7 +657,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     if ((P >> lane) & 1ull) {
                         const int idx = n + mbcnt(P);
                         G_TW(wave)[cell] = word_r | 2u;                           // :549
-                        stamp[(uint32_t)q] = id;
                         G_LST(wave)[idx & LMASK] = pack_xy(nx, ny);               // :551-556
                         if (wt) spill[(uint32_t)idx] = pack_xy(nx, ny);
                     }
@@ -624,7 +669,6 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     }
                     Ce += (double)pc2; Se += (double)ps;
                     n += np;
-                    g_ws[wave].dirty = 1;                // (all lanes, same value: see STAT)
                     flt_valid = false;                   // the region angle moved
                     gone = pcm;
                 }
@@ -680,13 +724,11 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     if (decided == 1) {
                         if (lane == l) {
                             G_TW(wave)[cell] = word_r | 2u;                       // :549
-                            stamp[(uint32_t)q] = id;
                             G_LST(wave)[n & LMASK] = pack_xy(nx, ny);             // :551-556
                             if (wt) spill[(uint32_t)n] = pack_xy(nx, ny);
                         }
                         Ce += (double)cl; Se += (double)sl;
                         n++;
-                        g_ws[wave].dirty = 1;
                         flt_valid = false;
                         gone |= ballot64(cand & (q == ql));
                     }
@@ -931,14 +973,16 @@ __device__ __noinline__ int radius_reduce(int cw_, int sx, int sy, int num, doub
 __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num, double regdeg, double denThre) {
     RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
     c.lane = (int)(threadIdx.x & 63u);
-    const int lane = c.lane, w = c.w;
+    const int lane = c.lane;
     STAT(ST_RRR, 1);
     double den = rec_density(num, g_ws[c.wave].rec);
     if (den > denThre) return num;                                                 // :760
     // keep the grow-order list for the marking loops before it gets reordered
     for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
-    invalidate_tiles(c);                                                           // (the scratch below takes the tile cache's place)
-    if (lane == 0) { g_ws[c.wave].has_copy = 1; g_ws[c.wave].dirty = 0; }
+    // curMap moves to HBM in full: the removals below clear bits there, the marking stages read them there (and the scratch of the
+    // parallel passes takes the tile cache's place)
+    flush_tiles(c);
+    if (lane == 0) g_ws[c.wave].has_copy = 1;
     wg_fence();
     const Rec rec = g_ws[c.wave].rec;
     const double ax = sx - rec.x1, ay = sy - rec.y1, bx = sx - rec.x2, by = sy - rec.y2;
@@ -991,7 +1035,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                     const bool nearb = ((msk[ci] >> lane) & 1ull) != 0ull;
                     const unsigned long long hm = ballot64((idx < K) & !nearb);
                     const uint32_t old = valid ? lget(c, idx) : 0u;
-                    if (valid & !nearb) c.stamp[(size_t)(old >> 16) * w + (old & 0xffffu)] = 0u;   // curMap = 0 (:781), every far point of this chunk
+                    if (valid & !nearb) tm_clear(c, (int)(old & 0xffffu), (int)(old >> 16));       // curMap = 0 (:781), every far point of this chunk
                     if ((idx < K) & !nearb) lset(c, idx, mv[nh + mbcnt(hm)]);                      // :782-785
                     nh += __builtin_popcountll(hm);
                 }
@@ -999,7 +1043,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                     const int idx = ci * 64 + lane;
                     if ((idx < num) & (((msk[ci] >> lane) & 1ull) == 0ull)) {
                         const uint32_t old = lget(c, idx);
-                        c.stamp[(size_t)(old >> 16) * w + (old & 0xffffu)] = 0u;
+                        tm_clear(c, (int)(old & 0xffffu), (int)(old >> 16));
                     }
                 }
                 num = K;
@@ -1010,7 +1054,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
             else {
                 const double ddx = sx, ddy = sy;
                 if (sqrt(ddx * ddx + ddy * ddy) > rad) {
-                    c.stamp[0] = 0u;                       // curMap(0, 0) = 0
+                    if (lane == 0) tm_clear(c, 0, 0);      // curMap(0, 0) = 0
                     num--;                                 // the last point is dropped from the list (its curMap bit stays)
                     STAT(ST_SENT, 1);
                 }
@@ -1030,8 +1074,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
             const double ddx = sx - px, ddy = sy - py;
             if (sqrt(ddx * ddx + ddy * ddy) > rad) {                               // :780
                 if (lane == 0) {
-                    const size_t q = (size_t)py * w + px;
-                    c.stamp[q] = 0u;                                               // curMap = 0 (:781)
+                    tm_clear(c, px, py);                                           // curMap = 0 (:781)
                     if (i == num) { lset(c, num - 1, 0u); }
                     else { lset(c, i, lget(c, num - 1)); lset(c, num - 1, 0u); }   // :782-785
                 }
@@ -1272,8 +1315,7 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
     c.lane = (int)(threadIdx.x & 63u);
     const int w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
-    wg_fence();                                   // the stamps written by grow() must have landed
-    if (c.lane == 0) g_ws[c.wave].dirty = 0;
+    wg_fence();                                   // (after RegionRadiusReducer: its removals from curMap must have landed)
     int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
     const int cnt = src ? src_cnt : g_ws[c.wave].gnum;
     const bool has_copy = g_ws[c.wave].has_copy != 0;
@@ -1282,7 +1324,9 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
         const uint32_t pkx = src ? src[k2] : (has_copy ? c.gcopy[k2] : lget(c, k2));
         const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
         const size_t q = (size_t)y * w + x;
-        if (src || c.stamp[q] == cur_id) {        // curMap == 1 only (src: a stashed list holds exactly those)
+        // curMap == 1 only: a stashed list (src) holds exactly those; the last grow's list is curMap unless RegionRadiusReducer has taken
+        // pixels out of it -- then curMap is in tmask (flush_tiles) and the grow-order copy is walked
+        if (src || !has_copy || tm_member(c, x, y, cur_id)) {
             const uint32_t old = c.pw[q];
             if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1); }
             else c.pw[q] = (old & ~3u) | kPwRejected;
@@ -1418,8 +1462,7 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
         if (m_off + gnum > gcap) { precise = false; m_off = 0; }
         if (gnum > gcap) redo = true;
         else {
-            wg_fence();                                // the stamps written by grow() must have landed
-            g_ws[wave].dirty = 0;
+            wg_fence();                                // (RegionRadiusReducer's removals from curMap must have landed)
             const uint32_t cur_id = g_ws[wave].cur_id;
             mcnt = 0;
             for (int base = 0; base < gnum; base += 64) {
@@ -1428,7 +1471,7 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
                 bool keep = false;
                 if (k2 < gnum) {
                     pkx = has_copy ? c.gcopy[k2] : lget(c, k2);
-                    keep = c.stamp[(size_t)(pkx >> 16) * w + (pkx & 0xffffu)] == cur_id;   // curMap == 1 only
+                    keep = !has_copy || tm_member(c, (int)(pkx & 0xffffu), (int)(pkx >> 16), cur_id);   // curMap == 1 only
                 }
                 const unsigned long long km = ballot64(keep);
                 if (keep) gl0[m_off + mcnt + __builtin_popcountll(km & ltm)] = pkx;
@@ -1526,13 +1569,13 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
     c.tep = b.tepoch + img * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
     c.sc = b.sc + img * npx;
-    c.stamp = b.stamps + (img * NW + wave) * npx;
+    c.tmask = b.stamps + (img * NW + wave) * (size_t)b.tm_stride;
     c.spill = b.spill + (img * NW + wave) * npx; c.gcopy = b.gcopy + (img * NW + wave) * npx;
     c.meta = b.wmeta + (img * NW + wave) * (size_t)b.mcap; c.mcap = b.mcap;
     c.tilesX = (w + 7) >> 3; c.id_base = id_base; c.id_budget = b.id_budget;
     if (lane == 0) {
         WState& ws = g_ws[wave];
-        ws.cur_id = id_base; ws.gnum = 0; ws.has_copy = 0; ws.dirty = 0; ws.cache_epoch = -1; ws.members_cached = 0;
+        ws.cur_id = id_base; ws.gnum = 0; ws.has_copy = 0; ws.tm_pending = 0; ws.cache_epoch = -1; ws.members_cached = 0;
         ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
     }
     c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;

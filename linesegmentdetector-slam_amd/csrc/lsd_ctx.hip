@@ -240,6 +240,10 @@ static int pool_for(const lsd_ctx* c, int n) {
     return p > 0 ? (int)p : 0;
 }
 
+// Words per wave of the member-mask array (4 per 8x8 tile) for any image of up to npx scaled pixels: tiles <= npx / 64 + (w + h) / 8 + 1,
+// and w, h <= 32766 (make_geom).
+static size_t tm_words(size_t npx) { return npx / 16 + 4 * 8200; }
+
 static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
     const size_t need_ws = (n + (size_t)pool_for(c, (int)n)) * (size_t)waves_for(c, (int)n);   // per-wave arrays: wave slots of the images and of the helper pool
     const bool grow_main = n > c->cap_n || npx > c->cap_npx || gpx > c->cap_gpx || need_ws > c->cap_ws;
@@ -253,8 +257,8 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->sc, tot));
         HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
-        HIPCHK(c, re_alloc(&c->stamps, ws * pp)); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
-        HIPCHK(c, hipMemset(c->stamps, 0, ws * pp * sizeof(uint32_t)));
+        HIPCHK(c, re_alloc(&c->stamps, ws * tm_words(pp))); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
+        HIPCHK(c, hipMemset(c->stamps, 0, ws * tm_words(pp) * sizeof(uint32_t)));
         c->run_id = 0;
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
@@ -469,6 +473,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
+    b.tm_stride = 4 * ((g.w + 7) >> 3) * ((g.h + 7) >> 3);
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
     b.max_lines = max_lines;
@@ -504,7 +509,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
         if (++c->run_id >= 1023u) {
-            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * c->cap_npx * sizeof(uint32_t), s));
+            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * tm_words(c->cap_npx) * sizeof(uint32_t), s));
             c->run_id = 1;
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));

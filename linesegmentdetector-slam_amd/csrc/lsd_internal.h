@@ -60,7 +60,8 @@ struct Buffers {
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
     uint16_t* ordv;        // n x npx : bin values
-    uint32_t* stamps;      // n x NW x npx : per-wave curMap stamps of the region stage
+    uint32_t* stamps;      // n x NW x tm_stride : per wave, the member masks of the tiles its cache has evicted (4 words per 8x8 tile: grow id, -, 64 bits)
+    int tm_stride;         // words per wave of the above: 4 x tiles of the scaled image
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
     uint32_t* gcopy;       // n x NW x npx : grow-order copy used when RegionRadiusReducer reorders the list
     float4* wmeta;         // n x NW x mcap : per list entry (unit sum vector, sin of the smallest slack) of its last neighbourhood test
