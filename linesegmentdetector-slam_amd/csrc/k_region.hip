@@ -603,7 +603,10 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         const int slot = tile_slot(tx, ty);
         const int cell = (slot << 6) | ((ny & 7) << 3) | (nx & 7);        // (in range even for !inb lanes)
         uint32_t word_r = G_TW(wave)[cell];
-        const int tagv = g_ttag[wave][slot];
+        int tagv = g_ttag[wave][slot];
+        // (both reads in flight before the tag is looked at: left alone the compiler moves the word's read behind the check -- it is read
+        //  again after a tile fetch anyway -- and a batch pays one more LDS round trip)
+        asm volatile("; tile word %0 and tag %1" : "+v"(word_r), "+v"(tagv));
         if (ballot64(inb & (tagv != tile_key(tx, ty)))) {
             if (!ensure_tiles(c, inb, nx, ny)) {         // slot conflict: one entry at a time
                 cnt = 1;
