@@ -579,11 +579,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
     [[maybe_unused]] long long bt_last = NOW();
     // One batch: up to 8 list entries (cnt of them, entry e of the batch = list index eidx in its 8 lanes) x 8 neighbours.
     // Returns the number of entries it dealt with (1 instead of cnt when their tiles collide in the cache).
-    // A sweep over a list longer than the ring reads the entries that have left it from HBM, 64 consecutive ones per load (pf: lane l
-    // holds entry pf_base + l), and hands them to the batches lane to lane -- not one round trip to HBM per batch of 8.
-    uint32_t pf = 0u;
-    int pf_base = 0, pf_end = 0;                             // the window's entries [pf_base, pf_end) had left the ring when it was loaded
-    auto batch = [&](int cnt, const int eidx, const bool direct, const bool from_pf, const float Cf, const float Sf, const float rV, const float Vn,
+    auto batch = [&](int cnt, const int eidx, const bool direct, const float Cf, const float Sf, const float rV, const float Vn,
                      const float nrat) -> int {
         [[maybe_unused]] const long long bt0 = NOW();
         BSTAT(ST_TSUMS, bt0 - bt_last);
@@ -592,8 +588,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
         // in a block of its own that also waits for it: a load whose register is still pending at the join would make the
         // compiler put an s_waitcnt vmcnt(0) in front of every batch, and that waits for the stamp stores of the batch before.
         uint32_t pk = G_LST(wave)[eidx & LMASK];
-        if (from_pf) pk = (uint32_t)__builtin_amdgcn_ds_bpermute((valid ? eidx - pf_base : 0) << 2, (int)pf);
-        else if (!direct) {                                  // entries that have left the ring (wave-uniform: only a list longer than the ring has any)
+        if (!direct) {                                       // entries that have left the ring (wave-uniform: only a list longer than the ring has any)
             const int lo = wt ? n - LCAP : 0;
             if (ballot64(valid & (eidx < lo))) {
                 uint32_t t = pk;
@@ -846,7 +841,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                     cnt = min(cnt, inv ? __builtin_ctzll(inv) : 64);
                 }
                 const int eidx = e < cnt ? (int)G_WL(wave)[wi + e] : 0;
-                wi += batch(cnt, eidx, false, false, Cf, Sf, rV, Vn, nrat);
+                wi += batch(cnt, eidx, false, Cf, Sf, rV, Vn, nrat);
             }
         }
         while (true) {                                       // ---- contiguous entries; n is live (:529) ----
@@ -854,17 +849,7 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
             i = uni(i);
             if (i >= n) break;
             const int cnt = min(8, n - i);
-            const bool direct = n - i <= LCAP;              // entries i .. n - 1 are all in the ring
-            bool from_pf = false;
-            if (!direct && i + 8 <= n - LCAP) {             // (wt holds: spill has every entry, and these were appended >= LCAP entries ago)
-                pf_base = uni(pf_base); pf_end = uni(pf_end);
-                if (i < pf_base || i + 8 > pf_end) {
-                    pf_base = i; pf_end = min(i + 64, n - LCAP);
-                    pf = spill[(uint32_t)min(i + lane, n - 1)];
-                }
-                from_pf = true;
-            }
-            i += batch(cnt, i + e, direct, from_pf, Cf, Sf, rV, Vn, nrat);
+            i += batch(cnt, i + e, n - i <= LCAP, Cf, Sf, rV, Vn, nrat);   // (direct: entries i .. n - 1 are all in the ring)
         }
         wl_cnt = nxt_cnt;
         sweep++;
