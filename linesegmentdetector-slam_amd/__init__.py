@@ -405,7 +405,7 @@ class Context:
             d = dict(zip(("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
                           "rrr_oob_reads", "cycles_refill", "cycles_total", "cycles_grow", "cycles_rect",
                           "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
-                          "wait_ring", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
+                          "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
                           "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
                           "wait_noseed", "requeued_ahead", "cycles_eval_at_cursor", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "help_exports", "help_evals", "help_reclaims",
                           "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),

@@ -360,6 +360,7 @@ __device__ __forceinline__ bool ensure_tiles(const RCtx& c, bool need, int px, i
                 nt++;
             }
         }
+        DSTAT(ST_WRING, nt);                               // (developer build: tiles fetched)
         // the tiles that make room leave their member flags in HBM (most have none: nothing is stored for them)
         #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -2358,7 +2359,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             {   // why this wave had nothing to do: no result slot for a waiting seed / the ring is full / no seed is left
                 const int old = lds_ld(&s_next);
                 const long long t_ = NOW();
-                const int why = old >= nseeds ? ST_WNOSEED : (lds_ld(&s_nbig) > 0 ? ST_WNOSLOT : (old + CH - f > RW ? ST_WRING : ST_WAIT));
+                const int why = old >= nseeds ? ST_WNOSEED : (lds_ld(&s_nbig) > 0 ? ST_WNOSLOT : ST_WAIT);
                 DSTAT(why, t_ - tl); tl = t_;
             }
 #else
