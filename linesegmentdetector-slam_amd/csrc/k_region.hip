@@ -271,6 +271,17 @@ __device__ __forceinline__ float min8(float v) {
     return v;
 }
 
+// sum over the 8 lanes of a group, every lane gets it (used where at most one lane holds a non-zero value: the sum is that value)
+__device__ __forceinline__ float sum8(float v) {
+    int t = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    t = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    t = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
+
 __device__ __forceinline__ double rl(double v, int l) {  // broadcast lane l (l wave-uniform)
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);
@@ -1564,6 +1575,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     uint32_t* const xr = (b.xq && !pool) ? b.xq + img * (size_t)kXStride : nullptr;        // this image's record of the help protocol
     uint32_t* const xhdr = b.xq ? b.xq + (size_t)nimg * kXStride : nullptr;                 // ... and the launch's
     if (threadIdx.x == 0 && xhdr && !pool) atomicAdd(&xhdr[0], 1u);
+    // when the launch's first workgroup started (s_memrealtime, 100 MHz, the same on every CU; low 32 bits | 1): what "running long"
+    // is measured against (below)
+    if (threadIdx.x == 0 && xhdr) atomicCAS(&xhdr[4], 0u, (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = g.w, h = g.h;
     const size_t npx = (size_t)g.npx;
@@ -1964,10 +1978,14 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             const int tn = (int)__builtin_amdgcn_s_memtime(), dt = tn - s_xt_last;
             if (dt > 200000) {
                 const int ic = lds_ld(&s_idlecnt);
-                // ... and only an image that has been running for a while asks at all (tun_gate, in 1024-clock units): the typical image is
-                // through before help could pay for the traffic it causes, the heavy ones are the ones that run long
+                // ... and only an image that has been running for a while asks at all: at least tun_gate (x 1024 clocks), and at least
+                // tun_share percent of the time since the launch began -- the typical image is through before help could pay for the
+                // traffic it causes; the ones that have been running for most of the launch are the ones it will end on
+                const uint32_t rt_now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                const uint32_t since_launch = rt_now - (ld_l2(&xhdr[4]) & ~1u), mine = rt_now - (uint32_t)rt_begin;
                 s_workbound = ((long long)(ic - s_xc_last) * (64 * LSD_REGION_WAIT_SLEEP + 1000) * 100 < (long long)dt * NW * b.tun_wb &&
-                               (long long)__builtin_amdgcn_s_memtime() - t_begin > (long long)b.tun_gate * 1024) ? 1 : 0;   // idle < tun_wb %
+                               (long long)__builtin_amdgcn_s_memtime() - t_begin > (long long)b.tun_gate * 1024 &&
+                               (unsigned long long)mine * 100ull >= (unsigned long long)since_launch * (unsigned)b.tun_share) ? 1 : 0;   // idle < tun_wb %
                 s_xc_last = ic; s_xt_last = tn;
             }
             const int nbg = s_workbound ? max(lds_ld(&s_nbig), 0) : 0;
@@ -2273,8 +2291,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                 const int l = has ? __builtin_ctz(byte) : 0;
                 const int src = (lane & 56) + l;
                 const bool acc = has & (((pm >> src) & 1ull) != 0ull);
-                const float cl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(cf)));
-                const float sl = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(sf)));
+                // (cos, sin) of the group's lane l in all its lanes: three DPP steps each instead of a round trip through the LDS crossbar
+                const float cl = sum8(kq == l ? cf : 0.0f);
+                const float sl = sum8(kq == l ? sf : 0.0f);
                 if (acc & (kq == l)) {
                     swin[cell] = word | 2u;                                   // :549
                     slst[gn] = (uint32_t)((ly << 4) | lx);                   // :551-556

@@ -25,6 +25,7 @@ struct lsd_ctx {
     int tun_help = -1;                                             // helper wavefronts per image (-1: default, 0: none)
     // developer experiments (environment variables read once, when the context is created; DESIGN_NOTES.md says what each was for)
     int tun_gate = 12000;                                          // an image asks for help once it has run for this long (x 1024 clocks: ~5 ms)
+    int tun_share = 0;                                             // ... and for at least this share (%) of the time since the launch began (LSD_REGION_SHARE)
     int pool_max_images = 4;                                       // calls with at most this many images get a pool of helper workgroups (LSD_REGION_POOL)
     int tun_early = 0, tun_wb = 10, tun_up = 32, tun_down = 96, tun_requeue = 1, tun_xpoll = 20000, tun_linger = 1000000, tun_stop = 0;
     uint32_t* xq = nullptr;
@@ -380,6 +381,7 @@ int lsd_create(lsd_ctx** out, int device) {
         env_int("LSD_REGION_EARLY", 0, 4096, &c->tun_early);        // helpers before every workgroup has its CU (measured: a loss)
         env_int("LSD_REGION_WB", 0, 100, &c->tun_wb);               // idle share (%) below which an image asks for help
         env_int("LSD_REGION_GATE", 0, 1 << 22, &c->tun_gate);       // ... once it has been running for this long (x 1024 clocks)
+        env_int("LSD_REGION_SHARE", 0, 100, &c->tun_share);
         env_int("LSD_REGION_POOL", 0, 1 << 20, &c->pool_max_images); // calls with at most this many images get helper-only workgroups
         env_int("LSD_REGION_UP", 0, 1 << 16, &c->tun_up);           // steps of the adaptive look-ahead
         env_int("LSD_REGION_DOWN", 0, 1 << 16, &c->tun_down);
@@ -485,7 +487,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
         b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
-        b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_gate = c->tun_gate; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
+        b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_gate = c->tun_gate; b.tun_share = c->tun_share; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
         b.tun_xpoll = c->tun_xpoll; b.tun_linger = c->tun_linger; b.tun_stop = c->tun_stop;
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
         b.npool = b.xq ? pool_for(c, n) : 0;

@@ -16,7 +16,7 @@ constexpr int kPTable = 16;                     // host-tabulated log(p), log10(
 //   [4] seeds waiting for a full evaluation; [R, 2R) requests (seed + 1, bit 31: taken by a helper); [2R, 3R) flags of the
 //   answers (seed + 1); [3R, 11R) the answers, 8 words each: result state, result slot, accept epoch of the snapshot, box (2),
 //   list sizes (R = kXReq).  After the n image records (kXHdr words): [0] workgroups started [1] images finished [2] length
-//   of the list of images that ask for help; the list (image + 1) follows.
+//   of the list of images that ask for help [3] early helper wavefronts [4] s_memrealtime of the launch's start | 1; the list (image + 1) follows.
 constexpr int kXStride = 768, kXReq = 64, kXHdr = 16;
 
 // Geometry + thresholds of one (cols, rows, params) configuration; computed on the host with the
@@ -80,6 +80,7 @@ struct Buffers {
     int tun_early;         // workgroups that may help while others still wait for a CU
     int tun_wb;            // an image asks for help while its waves idle less than this share of the time (percent)
     int tun_gate;          // ... and once it has been running for this long (1024-clock units)
+    int tun_share;         // ... and for at least this share (percent) of the time since the launch began
     int tun_up, tun_down;  // steps of the adaptive look-ahead (seeds): up when a wave finds nothing to do, down on a redo / discard
     int tun_requeue;       // results invalidated by a line are queued for another evaluation when the line is accepted (1) or found at the cursor (0)
     int tun_xpoll;         // shader clocks between two looks of a wave at the help protocol
