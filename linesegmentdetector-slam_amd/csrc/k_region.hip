@@ -1380,37 +1380,41 @@ __device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) 
 // grow's list and Refiner's regrow (their pixels decide whether the result is still valid at its turn), and the pixels to mark.
 // The outcome goes to g_eo[wave] (all lanes store the same values), the rectangle stays in g_ws[wave].rec.
 __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slot_) {
-    RCtx c = g_ctx[uni(cw_)];
-    c.lane = (int)(threadIdx.x & 63);
-    const int lane = c.lane, wave = c.wave, w = c.w;
+    // What lives across this function's calls is wave-uniform and kept in scalar registers (uni()): values in VECTOR registers that
+    // survive a call have to sit in callee-saved ones, which this function must then save and restore through scratch memory for ITS
+    // caller -- 59 registers per evaluation before this was done, the largest single writer of the stage's HBM traffic.  The wave's
+    // context is read from LDS where it is needed instead of being carried along.
+    const int wave = uni(cw_);
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = uni(g_ctx[wave].w), gcap = uni(g_ctx[wave].gcap);
     const uint32_t pp = (uint32_t)uni((int)pp_);
     const bool spec = uni(spec_) != 0;
     const int slot = uni(slot_);
-    const int gcap = c.gcap;
-    const double p_degThre = g_par[0], p_regThre = g_par[1], p_aliPro = g_par[2], p_denThre = g_par[3];
-    const unsigned long long ltm = (1ull << lane) - 1ull;
-    const int sx = (int)(pp % (uint32_t)w), sy = (int)(pp / (uint32_t)w);
+    const double p_degThre = uni(g_par[0]), p_regThre = uni(g_par[1]), p_aliPro = uni(g_par[2]), p_denThre = uni(g_par[3]);
+    const int sx = uni((int)(pp % (uint32_t)w)), sy = uni((int)(pp / (uint32_t)w));
     EvalOut& eo = g_eo[wave];
+#define EVAL_CTX() RCtx c = g_ctx[wave]; c.lane = lane
+#define EVAL_GL0() (g_ctx[wave].wslist + (size_t)slot * gcap)
 
     int outcome = 0, num = 0, num0 = 0, rec_pk = 0;
     double logNFA = 0;
-    const bool skip = (c.pw[pp] & 3u) != 0u;           // monotone: once used, always used (:222)
+    const bool skip = uni((int)(g_ctx[wave].pw[pp] & 3u)) != 0;   // monotone: once used, always used (:222)
     int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
     // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
-    uint32_t* const gl0 = c.wslist + (size_t)slot * gcap;
     int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
     bool regrown = false;
     if (!skip) {
         // RegionGrower -> RectangleConverter -> Refiner (:225-238) as a two-pass loop: pass 0 grows with the
         // global tolerance, pass 1 (only when the rectangle is too sparse, :829) regrows with the tolerance
         // re-estimated by Refiner (:833-857).
-        const double seedDeg = c.deg[pp];
+        const double seedDeg = uni(g_ctx[wave].deg[pp]);
         double tol = p_degThre, regdeg = seedDeg;
         bool done = false;
         for (int pass = 0; pass < 2 && !done; pass++) {
-            num = grow(c.wave, sx, sy, seedDeg, tol);                                  // :225 / :857
-            c.llo = g_ctx[wave].llo;                                                   // (which part of the new list is in the ring)
+            num = uni(grow(wave, sx, sy, seedDeg, tol));                               // :225 / :857
             if (pass == 0 && spec && num <= gcap) {                // keep the first list for the validation at the cursor
+                EVAL_CTX();
+                uint32_t* const gl0 = EVAL_GL0();
                 for (int k2 = lane; k2 < num; k2 += 64) gl0[k2] = lget(c, k2);
                 n1 = num;
             }
@@ -1419,42 +1423,45 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
                 num0 = num;
                 if (num < p_regThre) { done = true; break; }                      // :228 (not marked, Q5)
             } else if (num < 2) { outcome = 1; done = true; break; }              // :861
-            if (num > 1) { exact_sums(c.wave, num); regdeg = atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos); }   // reg.deg (:547, :581)
+            if (num > 1) { exact_sums(wave, num); regdeg = uni(atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos)); }   // reg.deg (:547, :581)
             else regdeg = seedDeg;
-            rect_convert(c.wave, num, regdeg, p_aliPro, 0, p_degThre);                 // :232 / :866 (p, prec still the defaults)
-            const double den = rec_density(num, g_ws[wave].rec);
+            rect_convert(wave, num, regdeg, p_aliPro, 0, p_degThre);                   // :232 / :866 (p, prec still the defaults)
+            const double den = uni(rec_density(num, g_ws[wave].rec));
             if (pass == 0) {
                 if (den >= p_denThre) break;                                      // :829 dense enough
                 if (spec) {                                                       // the regrow replaces this list
                     Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-                    fb = list_bbox(c.wave, num, fb, false);
-                    fx0 = fb.x0; fy0 = fb.y0; fx1 = fb.x1; fy1 = fb.y1;
+                    fb = list_bbox(wave, num, fb, false);
+                    fx0 = uni(fb.x0); fy0 = uni(fb.y0); fx1 = uni(fb.x1); fy1 = uni(fb.y1);
                 }
-                tol = refine_tol(c.wave, sx, sy, num, seedDeg);                        // :833-855
+                tol = uni(refine_tol(wave, sx, sy, num, seedDeg));                     // :833-855
             } else if (den < p_denThre) {                                         // :869-877
-                const int r = radius_reduce(c.wave, sx, sy, num, regdeg, p_denThre);   // (lst reordered: gcopy holds the grow-order list)
+                const int r = uni(radius_reduce(wave, sx, sy, num, regdeg, p_denThre));   // (lst reordered: gcopy holds the grow-order list)
                 if (r < 0) { num = -r - 1; outcome = 1; done = true; }
                 else num = r;
             }
         }
         if (!done) {
-            logNFA = improve(c.wave);                                                  // :240
+            logNFA = uni(improve(wave));                                               // :240
             outcome = logNFA <= 0 ? 2 : 3;                                        // :242
-            rec_pk = g_ws[wave].rec.pk;
+            rec_pk = uni(g_ws[wave].rec.pk);
         }
     }
     eo.skip = skip ? 1 : 0; eo.outcome = outcome; eo.num = num; eo.num0 = num0; eo.rec_pk = rec_pk; eo.logNFA = logNFA;
     eo.redo = 0; eo.precise = 0; eo.n1 = 0; eo.n2 = 0; eo.m_off = 0; eo.mcnt = num;
     if (!spec || skip) return;
 
-    const int gnum = g_ws[wave].gnum;                  // size of the last grow (grow order)
-    const bool has_copy = g_ws[wave].has_copy != 0;
+    const int gnum = uni(g_ws[wave].gnum);             // size of the last grow (grow order)
+    const bool has_copy = uni(g_ws[wave].has_copy) != 0;
     // box of the pixels of this evaluation's grown lists
     {                                                  // (RegionRadiusReducer reordered/shrunk lst: the grow-order copy then)
         Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
-        fb = list_bbox(c.wave, gnum, fb, has_copy);
+        fb = list_bbox(wave, gnum, fb, has_copy);
         eo.x0 = fb.x0; eo.y0 = fb.y0; eo.x1 = fb.x1; eo.y1 = fb.y1;
     }
+    EVAL_CTX();
+    uint32_t* const gl0 = EVAL_GL0();
+    const unsigned long long ltm = (1ull << lane) - 1ull;
     bool precise = n1 >= 0;
     int n2 = 0;
     if (regrown) {                                     // keep Refiner's regrow (in grow order, before any reduction) behind the first list
@@ -1495,6 +1502,8 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
         }
     }
     eo.precise = precise ? 1 : 0; eo.m_off = m_off; eo.mcnt = mcnt; eo.redo = redo ? 1 : 0;
+#undef EVAL_CTX
+#undef EVAL_GL0
 }
 
 // (developer build only: the seed loop can be cut short for the cost-probe experiments of DESIGN_NOTES.md; the product runs them all)
