@@ -230,15 +230,18 @@ enum { LSD_STAGE_ALL = 0, LSD_STAGE_GAUSS = 1, LSD_STAGE_GRAD = 2, LSD_STAGE_SOR
 int lsd_set_stop_after(lsd_ctx *ctx, int stage);
 /* Enables the per-seed trace buffer (LSD_DBG_SEEDS); costs one record store per grown seed. */
 int lsd_set_trace(lsd_ctx *ctx, int on);
-/* Region stage variant: 4 wavefronts per image (two images per CU) or 8 (one image per CU, ~1.4x lower latency per
- * image, images taken heaviest first).  0 (default) picks 8 while the batch has at most four images per CU (the step is
- * bounded by its heaviest image until then) and 4 beyond.  Results do not depend on the choice. */
+/* Region stage variant: 4 wavefronts per image (three images per CU: the throughput build) or 8 (one image per CU, ~1.5x lower
+ * latency per image, images taken heaviest first).  0 (default) picks 8 while the batch has at most four images per CU (the step is
+ * bounded by its heaviest image until then) and 4 beyond.  Results do not depend on the choice.  Set it before lsd_reserve: the
+ * per-wave workspace (8 B per scaled pixel and wavefront + result slots) is sized for the variant. */
 int lsd_set_region_waves(lsd_ctx *ctx, int waves);
-/* Help across workgroups in the region stage: wavefronts of workgroups whose image is finished evaluate seeds of the images
- * still running (up to `waves` helper wavefronts per image; default 24, 0: none, -1: back to the default).  It shortens ONE
- * batch (its last images no longer run on a CU each with the rest of the GPU idle).  A caller that keeps several batches
- * in flight -- one context and one stream per batch -- should switch it off: the next batch's workgroups fill the idle
- * CUs, and helpers would hold them (bench.py does exactly that).  Results do not depend on the setting. */
+/* Help across workgroups in the region stage: wavefronts of workgroups whose image is finished evaluate seeds of the images still
+ * running (up to `waves` helper wavefronts per image; default 24, 0: none, -1: back to the default); an image asks once it has run
+ * for ~5 ms with its own wavefronts busy.  It shortens ONE batch (its last images no longer run on a CU each with the rest of the GPU
+ * idle), and a call with up to four images also gets helper-only workgroups from the start (the reference's usage, one map per call:
+ * a heavy 2048 x 2048 map 77 -> 30 ms).  A caller that keeps several batches in flight -- one context and one stream per batch --
+ * should switch it off: the next batch's workgroups fill the idle CUs, and helpers would hold them (bench.py does exactly that).
+ * Results do not depend on the setting. */
 int lsd_set_region_help(lsd_ctx *ctx, int waves);
 /* Test hook: the region stage marks the pixels of the region it is growing with a fresh 32-bit id per grow; a wavefront that
  * uses up its 2^20 ids within one run clears its stamp array and starts over.  That takes more than a million grows by one
