@@ -330,6 +330,28 @@ def test_device_resident_batch_with_torch(maps, lsdmod, ctx, oracle):
         assert np.array_equal(d_ims[i].cpu().numpy(), ref["lineIm"])
 
 
+def test_line_raster_at_an_unaligned_address(maps, lsdmod, ctx, oracle):
+    """lineIm is cleared by the library's own 16-byte-per-lane kernel (k_clear16): a raster that starts at an odd address and has an odd
+    size gets its head and tail bytes too, and nothing outside it is touched."""
+    import torch
+    img = np.ascontiguousarray(maps["aisle2"][:301, :455])
+    rows, cols = img.shape
+    n = 3
+    d = torch.from_numpy(np.stack([img] * n)).cuda()
+    pad = 37
+    buf = torch.full((n * rows * cols + 2 * pad + 16,), 0xAB, dtype=torch.uint8, device="cuda")
+    base = buf.data_ptr() + pad + ((3 - (buf.data_ptr() + pad)) % 16)          # address = 3 (mod 16)
+    off = base - buf.data_ptr()
+    lines = torch.zeros((n, 256, 10), dtype=torch.int64, device="cuda"); cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.enqueue_device(d.data_ptr(), n, cols, rows, lines.data_ptr(), 256, cnt.data_ptr(), d_line_ims=base, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = oracle.lsd(img.copy())
+    got = buf.cpu().numpy()
+    assert (got[:off] == 0xAB).all() and (got[off + n * rows * cols:] == 0xAB).all()
+    for i in range(n):
+        assert np.array_equal(got[off + i * rows * cols: off + (i + 1) * rows * cols].reshape(rows, cols), ref["lineIm"]), i
+
+
 def test_full_size_batch_properties(maps, lsdmod, ctx, oracle):
     """BASELINE config 4 shape (2048x2048 tiles), a slice of the batch: image 0 is the unshifted aisle1
     tile whose reference answer is recorded; replicas must agree bit for bit; every output is a valid raster."""
