@@ -191,9 +191,10 @@ def cpu_baseline(size, first, sample=24, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128, help="timed steps (the timed region ends with the drain of the steps in flight -- ~one step latency, "
-                    "0.3 s at depth 8 -- so a short run under-reports the rate a service sees; 128 steps take ~6 s)")
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps (default: what the driver passes).  The timed region starts with an empty pipeline and ends "
+                    "with the drain of the steps in flight -- about one step latency, 0.3 s at depth 8 -- so a short run under-reports the rate a "
+                    "service sees: 20 steps ~45 ms per step, --steps 128 ~39")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--max-lines", type=int, default=1024)
@@ -206,6 +207,8 @@ def main():
     ap.add_argument("--waves", type=int, default=-1, choices=(-1, 0, 4, 8), help="wavefronts per image of the region stage in the timed region: 0 = the library's choice "
                     "(8 for this batch size: lowest latency of one batch), 4 = two images per CU (highest throughput per CU); -1 = 4 with several steps in flight, else 0")
     ap.add_argument("--help-waves", type=int, default=0, help="helper wavefronts per image (lsd_set_region_help) while several steps are in flight (experiments; 0 = off)")
+    ap.add_argument("--tail-help", type=int, default=0, help="experiments: the last N steps of the timed region are enqueued with the help across workgroups ON (no further "
+                    "step will come to fill the CUs their last images leave idle); measured with 20 steps at depth 8: 0 / 4 / 7 / 8 -> 44.9 / 45.3 / 46.8 / 68.4 ms per step")
     a = ap.parse_args()
 
     import torch
@@ -262,9 +265,13 @@ def main():
     # its communicator is bound to the torch.distributed group here (RCCL), a C++ host binds it with lsd_comm_from_rccl
     comm = ldist.torch_comm() if use_dist else None
 
-    def step(i, collect):
+    tail_help = max(0, a.tail_help) if depth > 1 else 0
+
+    def step(i, collect, last=False):
         j = i % depth
         l_, c_, im_ = outs[j]
+        if depth > 1:                                      # (a host-side setting of the context, read at the enqueue)
+            ctxs[j].set_region_help(-1 if last else a.help_waves)
         ctxs[j].enqueue_device(d_maps.data_ptr(), n, size, size, l_.data_ptr(), a.max_lines, c_.data_ptr(),
                                d_line_ims=None if im_ is None else im_.data_ptr(), stream=tstreams[j].cuda_stream)
         res = None
@@ -281,13 +288,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not a step: every context's first launch (module load, attribute calls, the first touch of its workspace) happens here,
+    # on one image, so that a warm-up shorter than the number of steps in flight does not leave first launches inside the timed region
+    for j in range(depth):
+        l_, c_, im_ = outs[j]
+        ctxs[j].enqueue_device(d_maps.data_ptr(), 1, size, size, l_.data_ptr(), a.max_lines, c_.data_ptr(),
+                               d_line_ims=None if im_ is None else im_.data_ptr(), stream=tstreams[j].cuda_stream)
+    barrier()
     for i in range(a.warmup):
         step(i, False)
     barrier()
     t0 = time.perf_counter()
     res = None
     for i in range(a.steps):
-        res = step(i, depth == 1)
+        res = step(i, depth == 1, last=i >= a.steps - tail_help)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -363,6 +377,8 @@ def main():
                        "rccl_gather_in_step": bool(use_dist),
                        "steps_in_flight": depth, "region_waves_per_image": waves if waves else 8,
                        "help_across_workgroups": bool(depth == 1 or a.help_waves),
+                       # the last steps of the timed region run with the help ON: nothing follows them that could fill the idle CUs
+                       "last_steps_with_help": tail_help,
                        # the steps in flight share one resident input, so the timed region runs WITHOUT LSD_FLAG_WRITEBACK_MAP: the
                        # observable in-place remap of the caller's maps (myLSD.cpp:135-142; ~0.3 ms of byte writes per step) is not in it
                        "writeback_map": False},

@@ -7,11 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 j = json.load(open(src))
 k = j["kernel_ms"]; one = j["one_step_at_a_time"]; dk = j["dominant_kernel"]; rf = j["roofline"]; cb = j.get("cpu_baseline", {}); m1 = j.get("map1", {})
+long_run = None
+lp = src.replace("_bench_n1.json", "_bench_n1_steps128.json")
+if lp != src and os.path.exists(lp):
+    long_run = json.load(open(lp))
 rows = [
     ("source", "`%s` (`python3 bench.py`, kernel sources sha %s)" % (os.path.relpath(src, ROOT), j.get("source_sha"))),
     ("timed region", "%d steps in flight, %d-wave region stage, help %s, %d timed steps after %d warm-up steps" % (
         j["config"]["steps_in_flight"], j["config"]["region_waves_per_image"], "on" if j["config"].get("help_across_workgroups") else "off", j["steps"], j["warmup"])),
     ("**`value`**", "**%.1f Gpix/s, %.1f ms per step, %.2f M lines/s** (%d lines per step)" % (j["value"] / 1e3, j["ms_per_step"], j["lines_per_s"] / 1e6, j["lines_per_step"])),
+    ("the same with 128 timed steps (the drain of the steps in flight amortised)", "**%.1f Gpix/s, %.1f ms per step, %.2f M lines/s** (`%s`)" % (
+        long_run["value"] / 1e3, long_run["ms_per_step"], long_run["lines_per_s"] / 1e6, os.path.relpath(lp, ROOT))) if long_run else ("long run", "n/a"),
     ("one step at a time", "%.1f ms = %.1f Gpix/s; kernels K1 %.2f (incl. the lineIm clear) / K2 %.2f / K3 %.2f / K4 %.1f / K5 %.2f ms" % (
         one["ms_per_step"], one["value"] / 1e3, k["gauss"], k["gradient"], k["sort"], k["region"], k["lines"])),
     ("`roofline` (K2)", "%.0f GB/s algorithmic = **%.3f** of 8 TB/s (launch %.3f ms); PMC traffic %s GB per launch; device copy in the same process %s GB/s" % (

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the profiles of a round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>      e.g. r04a  ->  gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
-# 1. the bench line (`python3 bench.py`, defaults: eight steps in flight on the 4-wave region stage, help off; per-kernel
-#    figures of the line from un-overlapped steps right after the timed region);
+# 1. the bench line (`python3 bench.py`, defaults: 20 timed steps, eight steps in flight on the 4-wave region stage, help off; per-kernel
+#    figures of the line from un-overlapped steps right after the timed region) and the same with 128 timed steps;
 # 2. rocprofv3 --kernel-trace --stats of the TIMED configuration (bench.py's defaults, --no-cpu-baseline)  -> <tag>_w4_pipeline8_*
 #    and of the same workload one step at a time (--pipeline 1: library defaults, 8 waves, help on)         -> <tag>_w8_pipeline1_*
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section) of both -> traffic json
@@ -11,7 +11,8 @@
 tag=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/${tag}_bench_n1.json 2> $O/${tag}_bench_n1.err
+python3 $R/bench.py > $O/${tag}_bench_n1.json 2> $O/${tag}_bench_n1.err                                      # 20 timed steps, 5 warm-up: the driver's invocation
+python3 $R/bench.py --steps 128 --warmup 16 --no-cpu-baseline > $O/${tag}_bench_n1_steps128.json 2> /dev/null   # the long-run rate (the drain amortised)
 for cfg in w4_pipeline8 w8_pipeline1; do
   if [ $cfg = w4_pipeline8 ]; then args="--steps 32 --warmup 16"; else args="--steps 3 --warmup 1 --pipeline 1"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_${cfg}_stats -o s -- python3 $R/bench.py $args --no-cpu-baseline > $O/${tag}_${cfg}_stats.log 2>&1
