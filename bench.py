@@ -28,8 +28,11 @@ import numpy as np
 
 # Throughput mode keeps several steps in flight, one stream each; the HIP runtime maps streams onto 4 hardware queues unless told
 # otherwise, and streams that share a queue run their kernels one after the other.  One queue per step in flight (read when the
-# runtime initialises, i.e. before torch touches the GPU).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# runtime initialises, i.e. before torch touches the GPU).  The timed region has 8 in flight; the projection
+# of the sharded job (strong_scaling_projection, throughput mode) up to 32.  Measured (tools/k20_sweep.sh, tools/cumask_probe.py):
+# 8 steps in flight run at the same rate on 8 and on 16 queues; 32 queues cost the single step with help 15 % and the driver's
+# 20-step run 8 %; 32 small steps in flight on 16 queues (two streams per queue) run as well as on 32, on 8 queues at half the rate.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -510,32 +513,55 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
             proj[str(world)] = {"max_shard_ms": max(ts), "min_shard_ms": min(ts), "speedup": t_all / max(ts)}
         # the same split in THROUGHPUT mode: what an N-GPU job sees when every rank keeps `depth` steps in flight on its shard
         # (contexts ctxs[], 4-wave region stage, help off -- the configuration of this line's `value`), ms per sharded step
-        if len(ctxs) > 1:
-            def run_shard_pipelined(lo, hi, steps=32):
-                for c_ in ctxs:
-                    c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
+        depth1 = len(ctxs)
+        if depth1 > 1:
+            # A rank of an N-GPU job has a shard of n / N images per step; to keep the GPU as full as the 1-GPU job does it keeps N times
+            # as many steps in flight (the same number of images, up to 32 steps).  The 1-GPU figure comes from the timed region's own
+            # contexts; they are then closed (a context's workspace is ~40 MB per image) and every shard size gets contexts, streams
+            # and outputs of its own, sized for the shard.
+            def run_pipelined(lo, hi, slots):
+                m, dw = hi - lo, len(slots)
                 def go(i):
-                    j = i % len(ctxs)
-                    l_, c2, im_ = outs[j]
-                    ctxs[j].enqueue_device(d_maps[lo:hi].data_ptr(), hi - lo, size, size, l_[lo:hi].data_ptr(), a.max_lines, c2[lo:hi].data_ptr(),
-                                           d_line_ims=None if im_ is None else im_[lo:hi].data_ptr(), stream=tstreams[j].cuda_stream)
-                for i in range(len(ctxs)):
+                    cx, st_, l_, c2, im_ = slots[i % dw]
+                    cx.enqueue_device(d_maps[lo:hi].data_ptr(), m, size, size, l_.data_ptr(), a.max_lines, c2.data_ptr(),
+                                      d_line_ims=None if im_ is None else im_.data_ptr(), stream=st_.cuda_stream)
+                for i in range(dw):
                     go(i)
                 torch.cuda.synchronize()
+                steps = 4 * dw
                 t1 = time.perf_counter()
                 for i in range(steps):
                     go(i)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t1) * 1e3 / steps
-            t1_all = run_shard_pipelined(0, n_total)
-            proj["1"]["pipelined_ms_per_step"] = t1_all
+            for c_ in ctxs:
+                c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
+            t1_all = run_pipelined(0, n_total, [(ctxs[j], tstreams[j]) + tuple(outs[j]) for j in range(len(ctxs))])
+            proj["1"].update({"pipelined_ms_per_step": t1_all, "pipelined_steps_in_flight": len(ctxs)})
+            for c_ in ctxs[1:]:
+                c_.close()
+            del ctxs[1:], outs[1:]
             for world in (2, 4, 8):
-                ts = [run_shard_pipelined(*ldist.shard_range(n_total, world, r)) for r in range(world)]
+                dw = min(depth1 * world, 32)
+                m = -(-n_total // world)
+                torch.cuda.empty_cache()                       # (the library allocates with hipMalloc: what torch has cached is not free for it)
+                slots = []
+                for j in range(dw):
+                    cx = lsd.Context(dev.index or 0)
+                    cx.set_region_help(a.help_waves); cx.set_region_waves(waves); cx.reserve(m, size, size)
+                    slots.append((cx, tstreams[j] if j < len(tstreams) else torch.cuda.Stream(device=dev), torch.zeros((m, a.max_lines, 10), dtype=torch.int64, device=dev),
+                                  torch.zeros(m, dtype=torch.int32, device=dev), None if a.no_lineim else torch.zeros((m, size, size), dtype=torch.uint8, device=dev)))
+                ts = [run_pipelined(*ldist.shard_range(n_total, world, r), slots) for r in range(world)]
                 proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
-                                         "pipelined_speedup": t1_all / max(ts)})
+                                         "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw})
+                for sl in slots:
+                    sl[0].close()
+                del slots
+            torch.cuda.empty_cache()
             ctx.set_region_help(-1); ctx.set_region_waves(0)
-        out["strong_scaling_projection"] = {"gpus": proj, "note_throughput_mode": "pipelined_*: every shard run with %d steps in flight (the timed region's configuration) on this one GPU; "
-                                            "a sharded job in throughput mode advances at its slowest shard's rate" % len(ctxs), "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
+        out["strong_scaling_projection"] = {"gpus": proj, "note_throughput_mode": "pipelined_*: every shard run on this one GPU in the timed region's configuration with pipelined_steps_in_flight steps in flight "
+                                            "(%d x the number of GPUs, at most 32: the same number of images in flight as the 1-GPU job); "
+                                            "a sharded job in throughput mode advances at its slowest shard's rate" % depth1, "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
                                             "the sharded step takes at least its slowest shard: the region stage gives one CU per image, so a shard "
                                             "cannot finish before its heaviest image does" % n_total}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

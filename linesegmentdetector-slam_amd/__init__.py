@@ -347,6 +347,13 @@ class Context:
     def synchronize(self):
         self._chk(self.L.lsd_synchronize(self.h))
 
+    def fetch_stats_block(self, n):
+        """The raw counter records (the values of fetch(i, DBG_STATS, ...), in its order) of the first n images of the last
+        batch as an (n, 48) int64 array, in one copy (developer probes)."""
+        a = np.zeros((n, 48), np.int64)
+        self._chk(self.L.lsd_debug_fetch(self.h, 0, DBG_STATS, a.ctypes.data, a.nbytes))
+        return a
+
     def timings(self):
         ms = (C.c_float * 6)()
         self._chk(self.L.lsd_last_timings(self.h, ms))

@@ -188,12 +188,26 @@ constexpr int WLW = (LSD_REGION_WLW + 3) & ~3;               // words of the wor
 constexpr int WCAP = 2 * WLW - 2;                            // its entries; [WCAP]: the dummy slot
 constexpr int kTwOff = LCAP + WLW;
 constexpr int kArenaWords = kTwOff + NT * 64 > kSmallWords ? kTwOff + NT * 64 : kSmallWords;
+#ifdef LSD_REGION_DYN_ARENA
+constexpr unsigned kDynLds = NW * kArenaWords * 4;
+#else
+constexpr unsigned kDynLds = 0;
+#endif
 constexpr int kMvCap = kArenaWords - LCAP - 1;               // RegionRadiusReducer's scratch: worklist + tile cache (+ a dummy slot)
 static_assert(WLW >= 192, "the NFA's column scan keeps 3 x 64 ints in the worklist's place");
+#ifdef LSD_REGION_DYN_ARENA
+// The arenas as dynamic LDS (the launch passes NW * kArenaWords * 4 bytes): the compiler then sees ~16 KB of static LDS and accepts a
+// register budget for four wavefronts per SIMD although the 50 KB a workgroup really uses admit three workgroups per CU -- the fourth
+// wavefront slot of every SIMD (128 registers) stays free for the kernels of other steps (K1, K2, K3, K5) that run beside this one.
+extern __shared__ __attribute__((aligned(16))) uint32_t g_arena_dyn[];
+#define G_ARENA(w) (g_arena_dyn + (w) * kArenaWords)
+#else
 __shared__ __attribute__((aligned(16))) uint32_t g_arena[NW][kArenaWords];
-#define G_LST(w) (&g_arena[w][0])
-#define G_WL(w) (reinterpret_cast<uint16_t*>(&g_arena[w][LCAP]))
-#define G_TW(w) (&g_arena[w][kTwOff])
+#define G_ARENA(w) (&g_arena[w][0])
+#endif
+#define G_LST(w) (G_ARENA(w))
+#define G_WL(w) (reinterpret_cast<uint16_t*>(G_ARENA(w) + LCAP))
+#define G_TW(w) (G_ARENA(w) + kTwOff)
 __shared__ int g_ttag[NW][NT];
 __shared__ unsigned long long g_stat[NW][kStatSlots];      // per-wave counters (see ST_* above); kept out of registers
 __shared__ WState g_ws[NW];
@@ -2092,8 +2106,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     int ncap = 1;                                           // a group gives its seed up when the region reaches ncap pixels
     if (g.regThre > 1.0 && g.degThre < 1.5) ncap = g.regThre >= (double)SCAP ? SCAP : (int)ceil(g.regThre);
     const float cos_tol_s = (float)g_tol0[2];
-    uint32_t* const swin = &g_arena[wave][grp * 256];       // this group's window (the arena holds no full evaluation meanwhile)
-    uint32_t* const slst = &g_arena[wave][8 * 256 + grp * SCAP];   // this group's list: ly << 4 | lx
+    uint32_t* const swin = G_ARENA(wave) + grp * 256;       // this group's window (the arena holds no full evaluation meanwhile)
+    uint32_t* const slst = G_ARENA(wave) + 8 * 256 + grp * SCAP;   // this group's list: ly << 4 | lx
     int gk = -1;                                            // seed of this lane's group, -1: idle
     int gn = 0, gi = 0, gex = 0, gwx = 0, gwy = 0, gsnap = 0;
     float gC = 0.0f, gS = 0.0f;                             // estimated sum vector of the group's region
@@ -2653,7 +2667,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
 
 #if LSD_REGION_NW == 8
 void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
-    hipLaunchKernelGGL(w8::k_region, dim3(n + b.npool), dim3(64 * w8::NW), 0, s, g, b, id_base);
+    hipLaunchKernelGGL(w8::k_region, dim3(n + b.npool), dim3(64 * w8::NW), w8::kDynLds, s, g, b, id_base);
 }
 // workspace is sized for the wider variant
 int region_slots() { return w8::NS; }
@@ -2661,7 +2675,7 @@ int region_waves() { return w8::NW; }
 int region_ring() { return w8::RW; }
 #else
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s) {
-    hipLaunchKernelGGL(w4::k_region, dim3(n + b.npool), dim3(64 * w4::NW), 0, s, g, b, id_base);
+    hipLaunchKernelGGL(w4::k_region, dim3(n + b.npool), dim3(64 * w4::NW), w4::kDynLds, s, g, b, id_base);
 }
 #endif
 

@@ -715,7 +715,10 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
             HIPCHK(c, hipMemcpy(&nseed, c->nseed + image, 4, hipMemcpyDeviceToHost));
             src = (const SeedRec*)c->seeds + off; need = (size_t)nseed * sizeof(SeedRec);
             break;
-        case LSD_DBG_STATS: src = c->stats + (size_t)image * kStatWords; need = 8 * kStatWords; break;
+        case LSD_DBG_STATS:                                           // (a larger `bytes` reads the records of the following images too)
+            src = c->stats + (size_t)image * kStatWords; need = 8 * kStatWords;
+            if (bytes > need) { const size_t all = (size_t)(c->last_n - image) * need; need = bytes < all ? bytes / need * need : all; }
+            break;
         default: return LSD_ERR_INVALID;
     }
     if (bytes < need) return LSD_ERR_INVALID;

@@ -41,8 +41,10 @@ if p:
     lat = " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["max_shard_ms"], p[g]["speedup"]) for g in ("1", "2", "4", "8"))
     rows.append(("strong-scaling projection, one step (slowest shard alone on this GPU)", lat))
     if "pipelined_ms_per_step" in p["1"]:
-        thr = "1: %.1f ms per step" % p["1"]["pipelined_ms_per_step"] + " / " + " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["pipelined_max_shard_ms_per_step"], p[g]["pipelined_speedup"]) for g in ("2", "4", "8"))
-        rows.append(("… in throughput mode (slowest shard, eight steps in flight)", thr))
+        thr = "1: %.1f ms per step (%d in flight)" % (p["1"]["pipelined_ms_per_step"], p["1"].get("pipelined_steps_in_flight", 8)) + " / " + " / ".join(
+            "%s: slowest shard %.1f ms, fastest %.1f (%.2f x; %d in flight)" % (g, p[g]["pipelined_max_shard_ms_per_step"], p[g]["pipelined_min_shard_ms_per_step"], p[g]["pipelined_speedup"],
+                                                                              p[g].get("pipelined_steps_in_flight", 8)) for g in ("2", "4", "8"))
+        rows.append(("… in throughput mode (every rank keeps the same number of images in flight: 8 × N steps, at most 32)", thr))
 table = "| | |\n|---|---|\n" + "\n".join("| %s | %s |" % r for r in rows)
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
