@@ -122,7 +122,13 @@ def cpu_baseline(size, first, sample=24, reps=5):
     from oracle import oracle
     oracle.build()
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    times, nl = _cpu_worker((cores[0], first, sample, size, reps))  # one pinned core: min and median of `reps` passes
+    times, nl = _cpu_worker((cores[0], first, sample, size, reps))  # one pinned core: min and median of `reps` passes (this process stays pinned until unpin() below)
+    def unpin():
+        # the bench process must not stay on one core: threads started later inherit the mask of the thread that starts them
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except (AttributeError, OSError):
+            pass
     px = sample * size * size / 1e6
     tmin, tmed = min(times), statistics.median(times)
     out = {"value": px / tmin, "unit": "Mpix/s", "cores": 1, "kind": "port",
@@ -149,6 +155,7 @@ def cpu_baseline(size, first, sample=24, reps=5):
         oracle.lsd(m, want_lineim=True)
         t0s.append(time.perf_counter() - t0)
     out["single_image_ms"] = min(t0s[1:]) * 1e3
+    unpin()
     try:                                                            # N-core figure: N independent pinned instances over disjoint images
         import multiprocessing as mp
         # how many cores this process may actually use: its affinity mask, cut down to the cgroup's CPU quota (a container that
@@ -253,7 +260,9 @@ def main():
     ctxs = [ctx] + [lsd.Context(local) for _ in range(depth - 1)]
     outs = [(torch.zeros((n, a.max_lines, 10), dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
              None if a.no_lineim else torch.zeros((n, size, size), dtype=torch.uint8, device=dev)) for _ in range(depth)]
-    tstreams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    # (all of torch's 32 pool streams are taken here, back to back: the projection of the sharded job below keeps up to 32 steps in
+    #  flight, and streams taken one by one between other allocations ended up unevenly spread over the hardware queues)
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(max(depth, 32))]
     d_lines, d_counts, d_ims = outs[0]
     stream = tstreams[0].cuda_stream
     for c_ in ctxs:
@@ -517,8 +526,10 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
         if depth1 > 1:
             # A rank of an N-GPU job has a shard of n / N images per step; to keep the GPU as full as the 1-GPU job does it keeps N times
             # as many steps in flight (the same number of images, up to 32 steps).  The 1-GPU figure comes from the timed region's own
-            # contexts; they are then closed (a context's workspace is ~40 MB per image) and every shard size gets contexts, streams
-            # and outputs of its own, sized for the shard.
+            # contexts; they are then closed (a context's workspace is ~40 MB per image) and every shard size gets contexts and outputs
+            # of its own, sized for the shard.  (In THIS process, after everything above, the 32-steps-in-flight runs come out 1.3-1.4 x
+            # slower than in a process that does nothing else -- tools/shard_probe.py, profiles/*_shard_probe.log, DESIGN_NOTES.md --
+            # so the figures for 4 and 8 GPUs here are the conservative ones.)
             def run_pipelined(lo, hi, slots):
                 m, dw = hi - lo, len(slots)
                 def go(i):
@@ -549,11 +560,12 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
                 for j in range(dw):
                     cx = lsd.Context(dev.index or 0)
                     cx.set_region_help(a.help_waves); cx.set_region_waves(waves); cx.reserve(m, size, size)
-                    slots.append((cx, tstreams[j] if j < len(tstreams) else torch.cuda.Stream(device=dev), torch.zeros((m, a.max_lines, 10), dtype=torch.int64, device=dev),
+                    slots.append((cx, tstreams[(j + depth1) % len(tstreams)], torch.zeros((m, a.max_lines, 10), dtype=torch.int64, device=dev),
                                   torch.zeros(m, dtype=torch.int32, device=dev), None if a.no_lineim else torch.zeros((m, size, size), dtype=torch.uint8, device=dev)))
                 ts = [run_pipelined(*ldist.shard_range(n_total, world, r), slots) for r in range(world)]
                 proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
-                                         "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw})
+                                         "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw,
+                                         "pipelined_shard_ms_per_step": [round(t, 2) for t in ts]})
                 for sl in slots:
                     sl[0].close()
                 del slots

@@ -20,8 +20,11 @@ def per_kernel(d, counter):
                 continue
             for k in KERNELS:
                 if k in row["Kernel_Name"]:
-                    acc[k].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+                    acc[k].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+    # launches over the whole batch only: bench.py's set-up runs one IMAGE per context (first launch, first touch of the workspace),
+    # and those launches must not dilute the average
+    full = {k: [c for g, c in v if g == max(g2 for g2, _ in v)] for k, v in acc.items()}
+    return {k: sum(v) / len(v) for k, v in full.items()}, {k: len(v) for k, v in full.items()}
 
 
 def source_sha():
@@ -37,7 +40,7 @@ def main():
     f, nf = per_kernel(fd, "FETCH_SIZE")
     w, nw = per_kernel(wd, "WRITE_SIZE")
     res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
-           "--no-cpu-baseline` (512 x 2048^2); counters are KB per dispatch, averaged over the launches of each kernel; "
+           "--no-cpu-baseline` (512 x 2048^2); counters are KB per dispatch, averaged over the whole-batch launches of each kernel (the one-image launches of the set-up are left out); "
            "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (confirmed for 8-B-per-lane loads with "
            "tools/pmc_calib.py: profiles/r01b_pmc_calib_*.csv)",
            "build": build, "source_sha": source_sha(), "kernels": {}}
