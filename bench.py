@@ -552,23 +552,27 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
             for c_ in ctxs[1:]:
                 c_.close()
             del ctxs[1:], outs[1:]
-            for world in (2, 4, 8):
-                dw = min(depth1 * world, 32)
-                m = -(-n_total // world)
-                torch.cuda.empty_cache()                       # (the library allocates with hipMalloc: what torch has cached is not free for it)
-                slots = []
-                for j in range(dw):
-                    cx = lsd.Context(dev.index or 0)
-                    cx.set_region_help(a.help_waves); cx.set_region_waves(waves); cx.reserve(m, size, size)
-                    slots.append((cx, tstreams[(j + depth1) % len(tstreams)], torch.zeros((m, a.max_lines, 10), dtype=torch.int64, device=dev),
-                                  torch.zeros(m, dtype=torch.int32, device=dev), None if a.no_lineim else torch.zeros((m, size, size), dtype=torch.uint8, device=dev)))
-                ts = [run_pipelined(*ldist.shard_range(n_total, world, r), slots) for r in range(world)]
-                proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
-                                         "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw,
-                                         "pipelined_shard_ms_per_step": [round(t, 2) for t in ts]})
-                for sl in slots:
-                    sl[0].close()
-                del slots
+            try:                                               # (outside the timed region: a projection that does not fit this device's
+                                                               #  memory must not take the line with it)
+                for world in (2, 4, 8):
+                    dw = min(depth1 * world, 32)
+                    m = -(-n_total // world)
+                    torch.cuda.empty_cache()                       # (the library allocates with hipMalloc: what torch has cached is not free for it)
+                    slots = []
+                    for j in range(dw):
+                        cx = lsd.Context(dev.index or 0)
+                        cx.set_region_help(a.help_waves); cx.set_region_waves(waves); cx.reserve(m, size, size)
+                        slots.append((cx, tstreams[(j + depth1) % len(tstreams)], torch.zeros((m, a.max_lines, 10), dtype=torch.int64, device=dev),
+                                      torch.zeros(m, dtype=torch.int32, device=dev), None if a.no_lineim else torch.zeros((m, size, size), dtype=torch.uint8, device=dev)))
+                    ts = [run_pipelined(*ldist.shard_range(n_total, world, r), slots) for r in range(world)]
+                    proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
+                                             "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw,
+                                             "pipelined_shard_ms_per_step": [round(t, 2) for t in ts]})
+                    for sl in slots:
+                        sl[0].close()
+                    del slots
+            except (lsd.LsdError, RuntimeError) as e:
+                proj["error_throughput_mode"] = str(e)[:300]
             torch.cuda.empty_cache()
             ctx.set_region_help(-1); ctx.set_region_waves(0)
         out["strong_scaling_projection"] = {"gpus": proj, "note_throughput_mode": "pipelined_*: every shard run on this one GPU in the timed region's configuration with pipelined_steps_in_flight steps in flight "

@@ -40,7 +40,7 @@ p = j.get("strong_scaling_projection", {}).get("gpus")
 if p:
     lat = " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["max_shard_ms"], p[g]["speedup"]) for g in ("1", "2", "4", "8"))
     rows.append(("strong-scaling projection, one step (slowest shard alone on this GPU)", lat))
-    if "pipelined_ms_per_step" in p["1"]:
+    if "pipelined_ms_per_step" in p["1"] and all("pipelined_speedup" in p[g] for g in ("2", "4", "8")):
         thr = "1: %.1f ms per step (%d in flight)" % (p["1"]["pipelined_ms_per_step"], p["1"].get("pipelined_steps_in_flight", 8)) + " / " + " / ".join(
             "%s: slowest shard %.1f ms, fastest %.1f (%.2f x; %d in flight)" % (g, p[g]["pipelined_max_shard_ms_per_step"], p[g]["pipelined_min_shard_ms_per_step"], p[g]["pipelined_speedup"],
                                                                               p[g].get("pipelined_steps_in_flight", 8)) for g in ("2", "4", "8"))
