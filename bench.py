@@ -527,10 +527,13 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
             # A rank of an N-GPU job has a shard of n / N images per step; to keep the GPU as full as the 1-GPU job does it keeps N times
             # as many steps in flight (the same number of images, up to 32 steps).  The 1-GPU figure comes from the timed region's own
             # contexts; they are then closed (a context's workspace is ~40 MB per image) and every shard size gets contexts and outputs
-            # of its own, sized for the shard.  (In THIS process, after everything above, the 32-steps-in-flight runs come out 1.3-1.4 x
-            # slower than in a process that does nothing else -- tools/shard_probe.py, profiles/*_shard_probe.log, DESIGN_NOTES.md --
-            # so the figures for 4 and 8 GPUs here are the conservative ones.)
+            # of its own, sized for the shard.
             def run_pipelined(lo, hi, slots):
+                # ms per step at the steady RATE of the pipeline: every step's completion is time-stamped (an event on its stream), and the
+                # rate is taken between the dw-th completion and the moment the first slot runs out of queued steps.  (Timing a fixed
+                # number of steps per slot instead measures the most crowded hardware queue: 32 streams are dealt onto 16 queues, not
+                # always two each -- rocprofv3's Queue_Id showed 3 + 1 on two of them after an earlier launch in the process -- and a
+                # rank that refills whichever slot is free does not wait for that queue.  DESIGN_NOTES.md, "The strong split".)
                 m, dw = hi - lo, len(slots)
                 def go(i):
                     cx, st_, l_, c2, im_ = slots[i % dw]
@@ -539,12 +542,22 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
                 for i in range(dw):
                     go(i)
                 torch.cuda.synchronize()
-                steps = 4 * dw
-                t1 = time.perf_counter()
+                steps = 6 * dw
+                ev0 = torch.cuda.Event(enable_timing=True)
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+                ev0.record(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize()
                 for i in range(steps):
                     go(i)
+                    evs[i].record(slots[i % dw][1])
                 torch.cuda.synchronize()
-                return (time.perf_counter() - t1) * 1e3 / steps
+                done = np.array([ev0.elapsed_time(e) for e in evs])                # ms since ev0, step i ran on slot i % dw
+                t_dry = min(done[j::dw].max() for j in range(dw))                  # the first slot to have nothing left
+                order = np.sort(done)
+                k1, k2 = dw, int(np.searchsorted(order, t_dry, side="right"))      # completions dw .. k2 lie in the steady window
+                if k2 - k1 < dw:                                                  # (a window too short to mean anything: the plain average)
+                    return float(order[-1]) / steps
+                return float(order[k2 - 1] - order[k1 - 1]) / (k2 - k1)
             for c_ in ctxs:
                 c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
             t1_all = run_pipelined(0, n_total, [(ctxs[j], tstreams[j]) + tuple(outs[j]) for j in range(len(ctxs))])

@@ -38,16 +38,25 @@ for N in Ns:
             c.enqueue_device(shard.data_ptr(), m, size, size, l.data_ptr(), 1024, cn.data_ptr(), d_line_ims=im.data_ptr(), stream=st.cuda_stream)
         for i in range(depth): go(i)
         torch.cuda.synchronize()
+        steps = 6 * depth
+        ev0 = torch.cuda.Event(enable_timing=True); evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev0.record(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(4 * depth): go(i)
+        for i in range(steps):
+            go(i); evs[i].record(slots[i % depth][1])
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) * 1e3 / (4 * depth), int(sum(int(s[3].sum()) for s in slots) / depth)
+        static = (time.perf_counter() - t0) * 1e3 / steps          # a fixed number of steps per slot: as slow as the most crowded hardware queue
+        done = np.array([ev0.elapsed_time(e) for e in evs])
+        t_dry = min(done[j::depth].max() for j in range(depth))     # the first slot to have nothing left
+        order = np.sort(done); k1, k2 = depth, int(np.searchsorted(order, t_dry, side="right"))
+        rate = (order[k2 - 1] - order[k1 - 1]) / max(k2 - k1, 1)    # ms per step at the steady rate (what a rank that refills free slots sees)
+        return rate, int(sum(int(s[3].sum()) for s in slots) / depth), static
     for name, pick in (("contiguous", lambda r: d[r * m:(r + 1) * m]), ("interleaved", lambda r: d[r::N].contiguous())):
         if only and name != only: continue
         res = [run(pick(r)) for r in range(N)]
         ts = [x[0] for x in res]
-        print("%d shards, %d steps in flight, %s: ms per step %s | max %.2f mean %.2f | lines %d" % (
-            N, depth, name, " ".join("%.1f" % t for t in ts), max(ts), sum(ts) / N, sum(x[1] for x in res)), flush=True)
+        print("%d shards, %d steps in flight, %s: ms per step at the steady rate %s | max %.2f mean %.2f | lines %d | fixed steps per slot: %s" % (
+            N, depth, name, " ".join("%.1f" % t for t in ts), max(ts), sum(ts) / N, sum(x[1] for x in res), " ".join("%.1f" % x[2] for x in res)), flush=True)
     for sl in slots: sl[0].close()
     del slots
     torch.cuda.empty_cache()
