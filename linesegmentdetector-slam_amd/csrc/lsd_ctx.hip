@@ -219,7 +219,8 @@ static int waves_for(const lsd_ctx* c, int n) {
     // 8 wavefronts per image (one image per CU) finish an image ~1.5x sooner; 4 (two images per CU) have the higher throughput.
     // While the batch is only a few images per CU its time is that of its heaviest images: 8.  Long batches: 4.
     // (the per-wave workspace -- stamps / spill / gcopy, 12 B per scaled pixel and wave, + result slots -- doubles with 8 waves:
-    //  18.5 GB for the 512 x 2048^2 bench batch, ~37 GB for 1024 such maps; if it cannot be allocated the context falls back to 4)
+    //  the whole workspace is 56 MB per 2048^2 map on 8 waves and 40 MB on 4 (tools/workspace_size.py: 28.6 / 20.3 GB for the bench
+    //  batch of 512); if the 8-wave workspace cannot be allocated the context falls back to 4)
     if (c->region_waves_mode == 8 || (c->region_waves_mode == 0 && !c->prefer4 && n <= 4 * c->num_cus)) return 8;
     return 4;
 }
