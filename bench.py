@@ -81,6 +81,21 @@ def source_sha():
     return h.hexdigest()[:12]
 
 
+def steady_rate_ms(done_ms, slots):
+    """ms per step at the steady rate of a pipeline with `slots` steps in flight: done_ms[i] = completion time of step i (which ran on
+    slot i % slots, slots refilled in order).  The rate is taken between the `slots`-th completion and the moment the first slot has
+    nothing left to run: the fill at the start and the drain at the end -- and, with a fixed number of steps per slot, the wait for
+    the slowest slot -- stay outside.  A window of fewer than `slots` completions falls back to last completion / steps."""
+    done = np.asarray(done_ms, dtype=np.float64)
+    steps = len(done)
+    t_dry = min(done[j::slots].max() for j in range(slots))
+    order = np.sort(done)
+    k1, k2 = slots, int(np.searchsorted(order, t_dry, side="right"))
+    if k2 - k1 < slots:
+        return float(order[-1]) / steps
+    return float(order[k2 - 1] - order[k1 - 1]) / (k2 - k1)
+
+
 def load_maps():
     z = np.load(os.path.join(ROOT, "tests", "golden", "maps.npz"))
     return {k: z[k] for k in z.files}
@@ -551,13 +566,7 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
                     go(i)
                     evs[i].record(slots[i % dw][1])
                 torch.cuda.synchronize()
-                done = np.array([ev0.elapsed_time(e) for e in evs])                # ms since ev0, step i ran on slot i % dw
-                t_dry = min(done[j::dw].max() for j in range(dw))                  # the first slot to have nothing left
-                order = np.sort(done)
-                k1, k2 = dw, int(np.searchsorted(order, t_dry, side="right"))      # completions dw .. k2 lie in the steady window
-                if k2 - k1 < dw:                                                  # (a window too short to mean anything: the plain average)
-                    return float(order[-1]) / steps
-                return float(order[k2 - 1] - order[k1 - 1]) / (k2 - k1)
+                return steady_rate_ms([ev0.elapsed_time(e) for e in evs], dw)     # ms since ev0; step i ran on slot i % dw
             for c_ in ctxs:
                 c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
             t1_all = run_pipelined(0, n_total, [(ctxs[j], tstreams[j]) + tuple(outs[j]) for j in range(len(ctxs))])

@@ -46,10 +46,7 @@ for N in Ns:
             go(i); evs[i].record(slots[i % depth][1])
         torch.cuda.synchronize()
         static = (time.perf_counter() - t0) * 1e3 / steps          # a fixed number of steps per slot: as slow as the most crowded hardware queue
-        done = np.array([ev0.elapsed_time(e) for e in evs])
-        t_dry = min(done[j::depth].max() for j in range(depth))     # the first slot to have nothing left
-        order = np.sort(done); k1, k2 = depth, int(np.searchsorted(order, t_dry, side="right"))
-        rate = (order[k2 - 1] - order[k1 - 1]) / max(k2 - k1, 1)    # ms per step at the steady rate (what a rank that refills free slots sees)
+        rate = bench.steady_rate_ms([ev0.elapsed_time(e) for e in evs], depth)   # what a rank that refills free slots sees
         return rate, int(sum(int(s[3].sum()) for s in slots) / depth), static
     for name, pick in (("contiguous", lambda r: d[r * m:(r + 1) * m]), ("interleaved", lambda r: d[r::N].contiguous())):
         if only and name != only: continue
