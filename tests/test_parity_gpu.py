@@ -205,6 +205,21 @@ def test_batch_equals_single(maps, lsdmod, ctx):
         assert np.array_equal(ims[i], im1)
 
 
+def test_counter_records_in_one_copy(maps, lsdmod, ctx):
+    """lsd_debug_fetch(LSD_DBG_STATS) with room for several images returns the records of the following images as well
+    (what the developer probes read a whole batch with): the same words as one fetch per image."""
+    src = maps["aisle2"][:600, :1600]
+    batch = np.stack([src, src[::-1].copy(), src[:, ::-1].copy()]).copy()
+    ctx.run_batch(batch.copy())
+    wh = lsdmod.scaled_size(1600, 600)
+    block = ctx.fetch_stats_block(3)
+    assert block.shape == (3, 48)
+    for i in range(3):
+        one = ctx.fetch(i, lsdmod.DBG_STATS, wh)
+        assert one["grow_calls"] == block[i, 0] and one["grown_px"] == block[i, 1] and one["nfa_calls"] == block[i, 2]
+        assert one["cycles_total"] == block[i, 8] and one["seeds"] == block[i, 15] and block[i, 15] > 0
+
+
 def test_deterministic(maps, lsdmod, ctx):
     a = ctx.run(maps["aisle3"].copy())
     b = ctx.run(maps["aisle3"].copy())
