@@ -12,7 +12,7 @@ ctx.set_region_waves(4); ctx.set_region_help(0)
 s = torch.cuda.current_stream().cuda_stream
 for i in [int(a) for a in sys.argv[1:]] or [1]:
     img = bench.make_image(maps, i, 2048)
-    for n in (1, 64, 256, 512, 768, 1536):
+    for n in [int(x) for x in os.environ.get("COPIES", "1,64,256,512,768,1536").split(",")]:
         d = torch.from_numpy(np.broadcast_to(img, (n, 2048, 2048)).copy()).cuda()
         lines = torch.zeros((n, 1024, 10), dtype=torch.int64, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
         best = 1e9
