@@ -127,7 +127,8 @@ typedef struct lsd_comm {
 } lsd_comm;
 /* Binds *out to an RCCL communicator (an ncclComm_t, passed as void*): rank / world from ncclCommUserRank / ncclCommCount,
  * all_gather = ncclAllGather(..., ncclInt8, comm, stream) -- RCCL over xGMI between the GPUs of a node.  The RCCL symbols are taken
- * from the calling process (the library the communicator belongs to), else from librccl.so.1; LSD_ERR_UNSUPPORTED without RCCL. */
+ * from the RCCL the calling process has loaded (the library the communicator belongs to; a second copy is never loaded);
+ * LSD_ERR_UNSUPPORTED if the process has none. */
 int lsd_comm_from_rccl(void *nccl_comm, lsd_comm *out);
 
 /* Sizes of the gathered arrays: *per_rank = images of the largest shard; *counts_words = world * (per_rank + 2) int32. */
@@ -137,11 +138,14 @@ int lsd_gather_layout(int n_total, int world, int *per_rank, size_t *counts_word
  * (n_local == the size lsd_shard_range gives comm->rank, else LSD_ERR_INVALID).  On `stream`, without host synchronisation:
  *   1. the records are packed on the device, image-major, into a slab of cap_rows records (rows past the rank's lines are zero);
  *   2. all-gather of the padded counts:  d_counts_all [world][per_rank + 2] int32 -- rank r's per-image counts (clamped to
- *      max_lines, zero-padded), then [per_rank] = rows in its slab, [per_rank + 1] = 1 if it had to drop rows (more than cap_rows
- *      lines, an image over max_lines, or an image the region stage gave up);
+ *      max_lines, zero-padded), then [per_rank] = rows in its slab, [per_rank + 1] = flags: bit 0 it had to drop rows (more than
+ *      cap_rows lines or an image over max_lines), bit 1 an image the region stage gave up (lsd_gather_unpack: LSD_ERR_CAPACITY
+ *      resp. LSD_ERR_INTERNAL, with everything that did arrive in its outputs);
  *   3. all-gather of the slabs:          d_slabs_all [world][cap_rows] lsd_line.
  * Image g of the batch (rank r = its shard, local index j) has its lines at d_slabs_all[r][sum of counts[r][0..j)].
- * ~22 MB per GPU and step for the 512 x 2048^2 bench batch at cap_rows = 512 per image. */
+ * ~22 MB per GPU and step for the 512 x 2048^2 bench batch at cap_rows = 512 per image.
+ * The packing stages through buffers of the CONTEXT: like lsd_enqueue_batch_device, one context serves one stream at a time -- a
+ * second hand-off from the same context is ordered behind the first one's collectives (an event), whatever its stream. */
 int lsd_gather_lines(lsd_ctx *ctx, const lsd_comm *comm, const lsd_line *d_lines, const int32_t *d_counts, int n_local, int max_lines,
                      int n_total, int cap_rows, int32_t *d_counts_all, lsd_line *d_slabs_all, void *stream);
 /* Host side of the hand-off: turns HOST copies of the two gathered arrays into offsets_out[n_total + 1] and (if lines_out is
@@ -248,6 +252,11 @@ int lsd_set_region_help(lsd_ctx *ctx, int waves);
  * uses up its 2^20 ids within one run clears its stamp array and starts over.  That takes more than a million grows by one
  * wavefront on one image; this lowers the budget (2 .. 0xFFFF0 grows) so that tests reach the path.  Results do not change. */
 int lsd_debug_set_stamp_budget(lsd_ctx *ctx, unsigned grows);
+/* Test / developer hook: a schedule setting of the region stage by name ("SOFT", "CLAIM", "FEED", "BIG", "EARLY", "WB", "GATE", "SHARE",
+ * "UP", "DOWN", "REQUEUE", "XPOLL", "LINGER", "HELP", "POOL"; csrc/lsd_ctx.hip: kTunings), clamped to its range.  None changes a
+ * result.  From the ENVIRONMENT the shipped library takes two settings only, when a context is created: LSD_REGION_HELP (as
+ * lsd_set_region_help) and LSD_REGION_POOL (calls with at most that many images, 0..16, default 4, get helper-only workgroups). */
+int lsd_debug_set_tuning(lsd_ctx *ctx, const char *name, int value);
 
 /* Copies an intermediate of image `image` of the LAST run/enqueue to host memory (synchronises).
  *   GAUSS/MAG/DEG  h*w doubles      (GaussImage / magMap / degMap, myLSD.cpp:143-147)

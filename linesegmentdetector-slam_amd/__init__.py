@@ -68,9 +68,12 @@ class lsd_comm(C.Structure):
 
 
 class LsdError(RuntimeError):
-    def __init__(self, status, msg):
+    """A non-zero status of the C ABI.  `partial`: where the C side says its outputs are valid nevertheless (LSD_ERR_CAPACITY /
+    LSD_ERR_INTERNAL of the gather, LSD_ERR_CAPACITY of FeatureScan), what the call would have returned."""
+    def __init__(self, status, msg, partial=None):
         super().__init__("lsd_hip status %d: %s" % (status, msg))
         self.status = status
+        self.partial = partial
 
 
 _lib = None
@@ -114,6 +117,8 @@ def load_library(path=None):
     L.lsd_set_region_waves.restype = i; L.lsd_set_region_waves.argtypes = [vp, i]
     L.lsd_set_region_help.restype = i; L.lsd_set_region_help.argtypes = [vp, i]
     L.lsd_debug_set_stamp_budget.restype = i; L.lsd_debug_set_stamp_budget.argtypes = [vp, C.c_uint]
+    if hasattr(L, "lsd_debug_set_tuning") or not os.environ.get("LSD_HIP_LIB"):
+        L.lsd_debug_set_tuning.restype = i; L.lsd_debug_set_tuning.argtypes = [vp, C.c_char_p, i]
     L.lsd_set_host_max_lines.restype = i; L.lsd_set_host_max_lines.argtypes = [vp, i]
     L.lsd_debug_fetch.restype = i; L.lsd_debug_fetch.argtypes = [vp, i, i, vp, sz]
     L.lsd_last_timings.restype = i; L.lsd_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
@@ -147,7 +152,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_set_host_max_lines",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
@@ -173,7 +178,8 @@ def gather_layout(n_total, world):
 
 def gather_unpack(counts_all, slabs_all, n_total, world, cap_rows):
     """lsd_gather_unpack on HOST copies of the gathered arrays (int32 [world, per + 2], LINE_DTYPE / 80-byte records [world, cap_rows]):
-    returns (offsets int32 [n_total + 1], lines LINE_DTYPE in global image order); raises LsdError(LSD_ERR_CAPACITY) if a rank dropped rows."""
+    returns (offsets int32 [n_total + 1], lines LINE_DTYPE in global image order); raises LsdError(LSD_ERR_CAPACITY) if a rank dropped rows
+    and LsdError(LSD_ERR_INTERNAL) if the region stage gave an image up -- the exception's `partial` holds what did arrive."""
     L = load_library()
     ca = np.ascontiguousarray(counts_all, np.int32)
     sl = np.ascontiguousarray(slabs_all).view(np.uint8).reshape(-1, 80)
@@ -182,6 +188,8 @@ def gather_unpack(counts_all, slabs_all, n_total, world, cap_rows):
     total = int(ca.reshape(world, per + 2)[:, :per].sum())
     lines = np.zeros(max(total, 1), LINE_DTYPE)
     st = L.lsd_gather_unpack(ca.ctypes.data, sl.ctypes.data, n_total, world, cap_rows, offs.ctypes.data, lines.ctypes.data, len(lines))
+    if st in (LSD_ERR_CAPACITY, LSD_ERR_INTERNAL):
+        raise LsdError(st, L.lsd_strerror(st).decode(), partial=(offs, lines[:offs[-1]]))
     if st != LSD_OK:
         raise LsdError(st, L.lsd_strerror(st).decode())
     return offs, lines[:offs[-1]]
@@ -314,12 +322,16 @@ class Context:
         lines = np.zeros((n, 360), LINE_DTYPE); pts = np.zeros((n, pts_cap, 3), np.float64)
         nl = np.zeros(n, np.int32); npt = np.zeros(n, np.int32); lp = np.zeros((n, 2), np.float64); sz = np.zeros((n, 2), np.int32)
         mp = lsd_map_param(int(map_param[0]), int(map_param[1]), float(map_param[2]), float(map_param[3]), float(map_param[4]))
-        # (more than 360 line records in a scan -- the reference would overrun its array there -- raises LsdError(LSD_ERR_CAPACITY))
-        self._chk(self.L.lsd_feature_scan_batch(self.h, sc.ctypes.data, ln.ctypes.data, n, stride, mp, int(region_point_limit), float(thre_line),
-                                                float(line_dist_thre_m), lines.ctypes.data, nl.ctypes.data, pts.ctypes.data, pts_cap,
-                                                npt.ctypes.data, lp.ctypes.data, sz.ctypes.data))
+        # (more than 360 line records in a scan -- the reference would overrun its array there -- raises LsdError(LSD_ERR_CAPACITY), with
+        #  the stored records, which the C side says are valid, in the exception's `partial`)
+        st = self.L.lsd_feature_scan_batch(self.h, sc.ctypes.data, ln.ctypes.data, n, stride, mp, int(region_point_limit), float(thre_line),
+                                           float(line_dist_thre_m), lines.ctypes.data, nl.ctypes.data, pts.ctypes.data, pts_cap,
+                                           npt.ctypes.data, lp.ctypes.data, sz.ctypes.data)
+        if st != LSD_ERR_CAPACITY:
+            self._chk(st)
         out = []
         for i in range(n):
+            nl[i] = min(int(nl[i]), 360)
             if npt[i] > pts_cap:
                 raise RuntimeError("scan %d marks %d pixels, more than pts_cap" % (i, npt[i]))
             p = pts[i, :npt[i]].copy()
@@ -328,6 +340,8 @@ class Context:
                 im[p[:, 1].astype(int), p[:, 0].astype(int)] = 255
             out.append(dict(linesInfo=lines[i, :nl[i]].copy(), len_linesInfo=int(nl[i]), scanImPoint=p, lidarPos=(float(lp[i, 0]), float(lp[i, 1])),
                             lineIm=im))
+        if st == LSD_ERR_CAPACITY:
+            raise LsdError(st, self.L.lsd_strerror(st).decode(), partial=out)
         return out
 
     def occupancy_to_map(self, grid_i8):
@@ -369,6 +383,10 @@ class Context:
     def set_host_max_lines(self, max_lines):
         """Line capacity per image of run / run_batch (default 8192); more lines -> LsdError(LSD_ERR_CAPACITY)."""
         self._chk(self.L.lsd_set_host_max_lines(self.h, max_lines))
+
+    def debug_set_tuning(self, name, value):
+        """Test / developer hook (lsd_debug_set_tuning): a schedule setting of the region stage by name; no result depends on any."""
+        self._chk(self.L.lsd_debug_set_tuning(self.h, name.encode(), int(value)))
 
     def debug_set_stamp_budget(self, grows):
         """Test hook (lsd_debug_set_stamp_budget): curMap stamp ids per wavefront and run before the stamps are cleared."""
@@ -417,7 +435,9 @@ class Context:
                           "wait_noseed", "requeued_ahead", "cycles_eval_at_cursor", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "help_exports", "help_evals", "help_reclaims",
                           "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
                          [int(x) for x in v]))
-            # smallest |logNFA| compared with 0 and smallest non-zero gap between two compared NFA values (inf: none seen)
+            d["nfa_bracket_misses"] = int(v[40])   # stopping tests of the NFA's tail left to the correctly rounded pow / log10 (an image the watchdog gave up keeps its record here instead)
+            # how close RectangleImprover's comparisons came to a tie, relative: smallest |logNFA| / logNT compared with 0, smallest
+            # non-zero |v - best| / max(|v|, |best|, logNT) of two compared NFA values (inf: none seen)
             for k in ("nfa_min_abs", "nfa_min_gap"):
                 enc = d.pop(k + "_enc")
                 d[k] = float("inf") if enc == 0 else float(np.array([0x7ff0000000000000 - enc], np.uint64).view(np.float64)[0])

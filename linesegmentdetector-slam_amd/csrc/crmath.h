@@ -1,4 +1,4 @@
-// crmath.h -- correctly-rounded sin / cos / atan / atan2 for fp64 on gfx950 (and, for testing, on the host).
+// crmath.h -- correctly-rounded sin / cos / atan / atan2 / exp / log / log10 / pow for fp64 on gfx950 (and, for testing, on the host).
 //
 // Why: the reference is built against glibc's libm, whose sin/cos/atan2 return the correctly rounded
 // result in all but very rare cases, while the device math library (OCML) differs from it by 1 ulp in
@@ -195,6 +195,140 @@ CRM_FN bool atan_cr(double v, double& out) {
     return atan2_cr(v, 1.0, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// exp / log / log10 / pow, correctly rounded (RectangleNFACalculator, myLSD.cpp:1028-1058: the binomial tail's first term
+// exp(log1Term), the returned -log10(binTail) - logNT, and -- behind a bracket of the fast device functions -- the pow / log10
+// of the tail's stopping test).  Same scheme as above: double-double evaluation (~2^-100), one rounding at the end.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// e^(xh + xl) = 2^e2 * (m.hi + m.lo) with m in [1, 2) (+-), |xh| <= ~800
+CRM_FN dd exp_dd(double xh, double xl, int& e2) {
+    const double kd = rint(xh * INV_LN2O64);
+    const int k = (int)kd;
+    // r = x - k ln2/64 (ln2/64 as three doubles, 159 bits): exact product + exact leading cancellation
+    const dd p0 = two_prod(kd, LN2O64_3[0]);
+    dd r = two_sum(xh, -p0.hi);
+    r = dd_add_d(r, -p0.lo);
+    r = dd_add(r, dd_neg(two_prod(kd, LN2O64_3[1])));
+    r = dd_add_d(r, -(kd * LN2O64_3[2]));
+    r = dd_add_d(r, xl);
+    // e^r, |r| <= ln2/128 (+): r^n/n! for n >= 7 is below 2^-65 (double is enough), the r^14 term below 2^-141
+    const double z = r.hi;
+    double q = EXP_C[13][0];
+    q = fma_(q, z, EXP_C[12][0]);
+    q = fma_(q, z, EXP_C[11][0]);
+    q = fma_(q, z, EXP_C[10][0]);
+    q = fma_(q, z, EXP_C[9][0]);
+    q = fma_(q, z, EXP_C[8][0]);
+    q = fma_(q, z, EXP_C[7][0]);
+    dd S = dd_add_d(dd{EXP_C[6][0], EXP_C[6][1]}, q * z);
+    S = dd_add(dd{EXP_C[5][0], EXP_C[5][1]}, dd_mul(S, r));
+    S = dd_add(dd{EXP_C[4][0], EXP_C[4][1]}, dd_mul(S, r));
+    S = dd_add(dd{EXP_C[3][0], EXP_C[3][1]}, dd_mul(S, r));
+    S = dd_add(dd{EXP_C[2][0], EXP_C[2][1]}, dd_mul(S, r));
+    S = dd_add_d(dd_mul(S, r), 1.0);
+    S = dd_add_d(dd_mul(S, r), 1.0);
+    const int j = k & 63;
+    e2 = (k - j) / 64;
+    return dd_mul(dd{EXP2_TAB[j][0], EXP2_TAB[j][1]}, S);
+}
+
+// RN((m.hi + m.lo) * 2^e) for m.hi in [0.5, 4): one rounding, also where the result is subnormal
+CRM_FN double round_scale(dd m, int e) {
+    const dd s = fast_two_sum(m.hi, m.lo);                      // s.hi = RN(m.hi + m.lo)
+    if (e > 1100) return __builtin_huge_val();
+    if (e < -1200) return 0.0;
+    if (e >= -1021 || s.hi >= ldexp(1.0, -1022 - e)) return ldexp(s.hi, e);   // normal (or overflow): the scaling is exact
+    // below 2^-1022: round to a multiple of 2^-1074.  a + b = the value in those units (both scalings are exact).
+    const int sh = e + 1074;
+    if (sh < -3) return 0.0;
+    const double a = ldexp(s.hi, sh), b = ldexp(s.lo, sh);
+    const double big = 0x1p52;
+    const double n = (a + big) - big;                           // RN(a) to an integer, ties to even
+    const dd t = two_sum(a - n, b);                             // what is left, exactly
+    double nn = n;
+    if (t.hi > 0.5 || (t.hi == 0.5 && t.lo > 0)) nn = n + 1.0;
+    else if (t.hi < -0.5 || (t.hi == -0.5 && t.lo < 0)) nn = n - 1.0;
+    else if (b != 0.0 && t.lo == 0.0 && fabs(t.hi) == 0.5 && fmod(n, 2.0) != 0.0) nn = n + (t.hi > 0 ? 1.0 : -1.0);   // an exact tie made by b
+    return ldexp(nn, -1074);
+}
+
+CRM_FN double exp_cr(double x) {
+    if (x != x) return x;
+    if (x > 710.0) return __builtin_huge_val();
+    if (x < -746.0) return 0.0;
+    int e2;
+    const dd m = exp_dd(x, 0.0, e2);
+    return round_scale(m, e2);
+}
+
+// log(x) as double-double, x > 0 finite (subnormals included)
+CRM_FN dd log_dd(double x) {
+    int E = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; E = -54; }
+    int ex;
+    const double M = frexp(x, &ex) * 2.0;                       // [1, 2)
+    E += ex - 1;
+    const int i = (int)((M - 1.0) * 128.0);                     // the 7 leading mantissa bits
+    if (i >= CRM_LOG_ISPLIT) E += 1;                            // M >= ~sqrt 2 counts as M / 2: LOG_T carries the - ln2
+    // u = M rc_i - 1 exactly (rc_0 = 1 and rc_127 = 1/2 exactly: no cancellation against T_i next to x = 1)
+    const dd p = two_prod(M, LOG_RC[i]);
+    const dd u = two_sum(p.hi - 1.0, p.lo);
+    // log1p(u) = u (1 + u (-1/2 + u (1/3 - ...))), |u| < 2^-7: u^(k-1)/k for k >= 9 is below 2^-59 (double), the k = 18 term below 2^-123
+    const double z = u.hi;
+    double q = LOG_C[17][0];
+    q = fma_(q, z, LOG_C[16][0]);
+    q = fma_(q, z, LOG_C[15][0]);
+    q = fma_(q, z, LOG_C[14][0]);
+    q = fma_(q, z, LOG_C[13][0]);
+    q = fma_(q, z, LOG_C[12][0]);
+    q = fma_(q, z, LOG_C[11][0]);
+    q = fma_(q, z, LOG_C[10][0]);
+    q = fma_(q, z, LOG_C[9][0]);
+    dd S = dd_add_d(dd{LOG_C[8][0], LOG_C[8][1]}, q * z);
+    S = dd_add(dd{LOG_C[7][0], LOG_C[7][1]}, dd_mul(S, u));
+    S = dd_add(dd{LOG_C[6][0], LOG_C[6][1]}, dd_mul(S, u));
+    S = dd_add(dd{LOG_C[5][0], LOG_C[5][1]}, dd_mul(S, u));
+    S = dd_add(dd{LOG_C[4][0], LOG_C[4][1]}, dd_mul(S, u));
+    S = dd_add(dd{LOG_C[3][0], LOG_C[3][1]}, dd_mul(S, u));
+    S = dd_add(dd{LOG_C[2][0], LOG_C[2][1]}, dd_mul(S, u));
+    S = dd_add_d(dd_mul(S, u), 1.0);
+    dd r = dd_mul(S, u);
+    r = dd_add(dd{LOG_T[i][0], LOG_T[i][1]}, r);
+    if (E != 0) {
+        const double Ed = (double)E;
+        dd a = two_prod(Ed, LN2_H32[1]);
+        a = dd_add_d(a, Ed * LN2_H32[2]);
+        a = dd_add_d(a, Ed * LN2_H32[0]);                       // (|E| < 2^11) x (32 bits): exact
+        r = dd_add(a, r);
+    }
+    return r;
+}
+
+CRM_FN double log_cr(double x) {
+    if (x != x || x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_huge_val();
+    if (x > 1.7976931348623157e308) return x;
+    const dd r = log_dd(x);
+    return r.hi + r.lo;
+}
+CRM_FN double log10_cr(double x) {
+    if (x != x || x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_huge_val();
+    if (x > 1.7976931348623157e308) return x;
+    const dd r = dd_mul(log_dd(x), dd{INV_LN10[0], INV_LN10[1]});
+    return r.hi + r.lo;
+}
+// x^y for finite x > 0 and finite y (the NFA raises a ratio in (0, 1) to a pixel count)
+CRM_FN double pow_cr(double x, double y) {
+    if (y == 0.0 || x == 1.0) return 1.0;
+    const dd t = dd_mul_d(log_dd(x), y);
+    if (t.hi > 710.0) return __builtin_huge_val();
+    if (t.hi < -746.0) return 0.0;
+    int e2;
+    const dd m = exp_dd(t.hi, t.lo, e2);
+    return round_scale(m, e2);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // First-stage evaluations (Ziv's strategy).  The double-double routines above cost ~900 fp64 instructions per call; the
@@ -311,6 +445,70 @@ CRM_FN bool atan2_fast(double y, double x, double& out, dd* raw = nullptr) {
     const bool ok = round_certain(R.hi, R.lo, fabs(R.hi) * 0x1p-68, r);
     out = signbit(y) ? -r : r;
     return ok;
+}
+
+// exp(x), first stage: the same reduction and table as exp_dd with the series in double beyond r^2 / 2 (~2^-74 relative).  Answers only
+// where the result is a normal number and its rounding is certain; then it is the value of exp_cr, bit for bit.
+CRM_FN bool exp_fast(double x, double& out, dd* raw = nullptr) {
+    if (!(x > -700.0 && x < 700.0)) return false;                // (NaN, overflow, subnormal results: full evaluation)
+    const double kd = rint(x * INV_LN2O64);
+    const int k = (int)kd;
+    // r = x - k ln2/64 from the first 106 bits of ln2/64: absolute error <= 2^-96 (|k| < 2^16: 2^-100 from the dropped word, the rest
+    // from the rounding of the low part)
+    const dd p0 = two_prod(kd, LN2O64_3[0]);
+    const dd r0 = two_sum(x, -p0.hi);
+    const double rl0 = fma_(-kd, LN2O64_3[1], r0.lo - p0.lo);
+    const dd r = fast_two_sum(r0.hi, rl0);
+    const double z = r.hi;
+    // e^r = 1 + r + r^2/2 + z^3 (1/6 + z (1/24 + ... + z^4/5040)): |r| <= ln2/128 (+), the z^8 term is 2^-75; r^2/2 in double-double
+    const double P = (z * z) * z * fma_(z, fma_(z, fma_(z, fma_(z, EXP_C[7][0], EXP_C[6][0]), EXP_C[5][0]), EXP_C[4][0]), EXP_C[3][0]);
+    const dd q = two_prod(z, z);
+    const double sq_hi = 0.5 * q.hi, sq_lo = 0.5 * fma_(2.0 * z, r.lo, q.lo);
+    const dd s1 = fast_two_sum(1.0, z);
+    const dd s2 = two_sum(s1.hi, sq_hi);
+    const double lo = (s1.lo + s2.lo) + ((r.lo + sq_lo) + P);
+    const int j = k & 63;
+    const dd m = dd_mul_lite(dd{EXP2_TAB[j][0], EXP2_TAB[j][1]}, dd{s2.hi, lo});
+    if (raw) *raw = m;
+    double v;
+    if (!round_certain(m.hi, m.lo, fabs(m.hi) * 0x1p-70, v)) return false;
+    out = ldexp(v, (k - j) / 64);                                // |x| < 700: a normal number, the scaling is exact
+    return true;
+}
+
+// log10(x), first stage, for normal x > 0 (2^-65 |u| + 2^-84 (|E| + 1) absolute before the conversion; see the error bound below)
+CRM_FN bool log10_fast(double x, double& out, dd* raw = nullptr, double* errb = nullptr) {
+    if (!(x >= 0x1p-1022 && x <= 1.7976931348623157e308)) return false;
+    int ex;
+    const double M = frexp(x, &ex) * 2.0;                       // [1, 2)
+    int E = ex - 1;
+    const int i = (int)((M - 1.0) * 128.0);
+    if (i >= CRM_LOG_ISPLIT) E += 1;
+    const dd p = two_prod(M, LOG_RC[i]);
+    const dd u = two_sum(p.hi - 1.0, p.lo);                      // exact, |u| < 2^-7
+    const double z = u.hi;
+    // log1p(u) = u - u^2/2 + z^3 (1/3 - z/4 + ... - z^7/10): the u^11 term is 2^-70 |u| / 11; u^2/2 in double-double
+    double P = LOG_C[10][0];
+    P = fma_(P, z, LOG_C[9][0]); P = fma_(P, z, LOG_C[8][0]); P = fma_(P, z, LOG_C[7][0]); P = fma_(P, z, LOG_C[6][0]);
+    P = fma_(P, z, LOG_C[5][0]); P = fma_(P, z, LOG_C[4][0]); P = fma_(P, z, LOG_C[3][0]);
+    P = (z * z) * z * P;
+    const dd q = two_prod(z, z);
+    const double sq_hi = 0.5 * q.hi, sq_lo = 0.5 * fma_(2.0 * z, u.lo, q.lo);
+    const dd b = two_sum(z, -sq_hi);
+    const double blo = b.lo + ((u.lo - sq_lo) + P);
+    // + T_i + E ln2 (E x the 32-bit head of ln2 is exact)
+    const double Ed = (double)E;
+    const dd a = two_sum(Ed * LN2_H32[0], LOG_T[i][0]);
+    const double alo = a.lo + fma_(Ed, LN2_H32[1], LOG_T[i][1]);
+    const dd s = two_sum(a.hi, b.hi);
+    const dd R = fast_two_sum(s.hi, s.lo + (alo + blo));
+    const dd R10 = dd_mul_lite(R, dd{INV_LN10[0], INV_LN10[1]});
+    // error: series + roundings of the log1p part < 2^-66 |u| (the cubic term's rounding, 2^-52 |u|^3 / 3, leads; measured: 0.2 of the
+    // bound below), the table and E ln2 part <= 2^-84 (|E| + 1), the conversion 2^-100 relative
+    const double err = (fabs(z) * 0x1p-65 + (fabs(Ed) + 1.0) * 0x1p-84) * 0.5 + fabs(R10.hi) * 0x1p-98;
+    if (raw) *raw = R10;
+    if (errb) *errb = err;
+    return round_certain(R10.hi, R10.lo, err, out);
 }
 
 }  // namespace crm

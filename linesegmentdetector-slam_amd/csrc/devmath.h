@@ -1,6 +1,7 @@
 // devmath.h -- the transcendental functions used on the LSD path, glibc-compatible rounding.
 // sin/cos/atan/atan2 go through crmath.h (correctly rounded, see there for why); the rare inputs it
 // declines (non-finite, |x| > 64, subnormal range) fall back to the device math library.
+// exp / log10 / pow (RectangleNFACalculator): correctly rounded likewise (exp_g, log10_g, pow_g).
 #pragma once
 #include "crmath.h"
 
@@ -32,5 +33,19 @@ __device__ inline double atan_g(double v) {
     if (!crm::atan_cr(v, r)) r = atan(v);
     return r;
 }
+
+// RectangleNFACalculator's libm calls (myLSD.cpp:1034, :1040, :1052-1053, :1057), correctly rounded.  Out of line: ~1.5 KB each, called
+// twice per rectangle rating (the pow / log10 of the tail's stopping test only where the fast device functions cannot decide it).
+__device__ __noinline__ double exp_g(double x) {
+    double r;
+    if (crm::exp_fast(x, r)) return r;                         // first stage (Ziv): certain roundings only
+    return crm::exp_cr(x);
+}
+__device__ __noinline__ double log10_g(double x) {
+    double r;
+    if (crm::log10_fast(x, r)) return r;
+    return crm::log10_cr(x);
+}
+__device__ __noinline__ double pow_g(double x, double y) { return crm::pow_cr(x, y); }
 
 }  // namespace lsdhip

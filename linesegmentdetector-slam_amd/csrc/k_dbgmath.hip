@@ -16,6 +16,9 @@ __global__ void k_dbgmath(int fn, const double* __restrict__ a, const double* __
         const float r = af * 0.15915494309189535f;
         o0[i] = (double)__builtin_amdgcn_sinf(r); o1[i] = (double)__builtin_amdgcn_cosf(r);
     }
+    else if (fn == 4) { o0[i] = exp_g(a[i]); o1[i] = exp(a[i]); }                     // correctly rounded | the device math library's
+    else if (fn == 5) { o0[i] = log10_g(a[i]); o1[i] = log10(a[i]); }
+    else if (fn == 6) { o0[i] = pow_g(a[i], b[i]); o1[i] = pow(a[i], b[i]); }
     else { o0[i] = atan_g(a[i]); o1[i] = 0; }
 }
 

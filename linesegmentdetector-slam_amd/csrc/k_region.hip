@@ -124,6 +124,7 @@ struct RCtx {
     uint32_t id_budget;  // grows a wave may number before it has to clear its member masks (< 2^20: the next run's ids start there)
     double logNT;
     const double* lgamma;
+    int lg_count;
     const double* ptab;
     uint32_t* wslist;    // this wave's result slots: [NS][gcap] list entries
     int gcap;
@@ -133,7 +134,7 @@ struct RCtx {
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
        ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_COUNT };
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_COUNT };
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
@@ -1123,10 +1124,11 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
 }
 
 // ---------------------------------------------------------------------------------------------
-// LogGammaCalculator (:882-924): integers below kLgTable come from the host-computed table
+// LogGammaCalculator (:882-924): a look-up in the host-computed table (lsd_ctx.hip sizes it for every pixel count a rectangle of
+// the image can have; only images of more than kLgTableMax scaled pixels can get past it, and then with the device's own log / sinh / pow)
 // ---------------------------------------------------------------------------------------------
 __device__ double log_gamma_dev(const RCtx& c, int x) {
-    if (x >= 0 && x < kLgTable) return c.lgamma[x];
+    if (x >= 0 && x < c.lg_count) return c.lgamma[x];
     const double xd = x;
     return 0.918938533204673 + (xd - 0.5) * log(xd) - xd +
            0.5 * xd * log(xd * sinh(1.0 / xd) + 1.0 / (810 * pow(xd, 6.0)));
@@ -1135,7 +1137,9 @@ __device__ double log_gamma_dev(const RCtx& c, int x) {
 // ---------------------------------------------------------------------------------------------
 // RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
+// host_only: the value is made of host-computed numbers alone (logNT, log10 p: the reference's own libm) -- no device-evaluated function
+__device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, bool& host_only) {
+    host_only = true;
     const int lane = c.lane, xLim = c.w, yLim = c.h;
     const double logNT = c.logNT;
     STAT(ST_NFA, 1);
@@ -1216,30 +1220,53 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec) {
     const double proTerm = rec.p / (1.0 - rec.p);
     const double log1Coef = log_gamma_dev(c, all + 1) - log_gamma_dev(c, ali + 1) - log_gamma_dev(c, all - ali + 1);
     const double log1Term = log1Coef + ali * logp + (all - ali) * log1mp;          // :1033
-    double term = exp(log1Term);
+    // From here on the reference calls exp, log10 and pow.  What reaches the result -- the first term and the logarithm of the tail --
+    // is evaluated correctly rounded (exp_g, log10_g: crmath.h); pow and log10 inside the loop only decide when the sum stops, and that
+    // decision is taken from the device math library's values where a bracket around them (kOcmlBracket, many times their error:
+    // tests/test_parity_gpu.py::test_device_libm_is_inside_the_nfa_bracket) leaves no doubt, from the correctly rounded values otherwise.
+    double term = exp_g(log1Term);
     const double eps = 2.2204e-16;
     if (fabs(term) < 100 * eps) {                                                  // :1037-1043
-        if (ali > all * rec.p) return -log10(term) - logNT;
+        if (ali > all * rec.p) { host_only = false; return -log10_g(term) - logNT; }
         return -logNT;
     }
+    host_only = false;
     double binTail = term;
     const double tole = 0.1;
+    constexpr double kOcmlBracket = 0x1p-44, kTiny = 0x1p-1000;
     for (int i = ali + 1; i <= all; i++) {                                         // :1046-1056
         const double binTerm = (all - i + 1) / (i * 1.0);
         const double multTerm = binTerm * proTerm;
         term *= multTerm;
         binTail += term;
         if (binTerm < 1) {
-            const double err = term * ((1 - pow(multTerm, (double)(all - i + 1))) / (1.0 - multTerm) - 1);
-            if (err < tole * fabs(-log10(binTail) - logNT) * binTail) break;
+            // err < tole * |-log10(binTail) - logNT| * binTail ?  (:1052-1053)  Every operation of the two sides is monotone in the value
+            // of pow resp. log10, so the sides at the ends of the brackets enclose the sides at the correctly rounded values.
+            const double N = (double)(all - i + 1), om = 1.0 - multTerm;
+            const double Pd = pow(multTerm, N), Ld = log10(binTail);
+            const double Pe = Pd * kOcmlBracket + kTiny, Le = fabs(Ld) * kOcmlBracket + kTiny;
+            const double err_hi = term * ((1 - (Pd - Pe)) / om - 1), err_lo = term * ((1 - (Pd + Pe)) / om - 1);
+            const double a1 = -(Ld - Le) - logNT, a2 = -(Ld + Le) - logNT;
+            const double f1 = fabs(a1), f2 = fabs(a2);
+            const double rhs_hi = tole * fmax(f1, f2) * binTail;
+            const double rhs_lo = (a1 > 0) == (a2 > 0) && a1 != 0 && a2 != 0 ? tole * fmin(f1, f2) * binTail : 0.0;
+            bool stop;
+            if (err_hi < rhs_lo) stop = true;
+            else if (!(err_lo < rhs_hi)) stop = false;
+            else {
+                STAT(ST_NFASLOW, 1);                        // (stopping tests of the tail the bracket could not decide)
+                const double err = term * ((1 - pow_g(multTerm, N)) / om - 1);
+                stop = err < tole * fabs(-log10_g(binTail) - logNT) * binTail;
+            }
+            if (stop) break;
         }
     }
-    return -log10(binTail) - logNT;
+    return -log10_g(binTail) - logNT;
 }
 
-__device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec) {
+__device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec, bool& host_only) {
     [[maybe_unused]] const long long t0 = NOW();
-    const double v = rect_nfa_impl(c, rec);
+    const double v = rect_nfa_impl(c, rec, host_only);
     PSTAT(ST_TNFA, NOW() - t0);
     return v;
 }
@@ -1278,9 +1305,16 @@ __device__ __noinline__ double improve(int cw_) {
             } else eval = false;
         }
         if (!eval) continue;
-        const double v = rect_nfa(c, r);
-        STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v)));                 // (v is compared with 0: :1075, :242)
-        if (step > 0 && v != bestNFA) STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA)));
+        bool host_only;
+        const double v = rect_nfa(c, r, host_only);
+        // how close the two comparisons below come to a tie, RELATIVE to the magnitudes that set their rounding noise (logNT and the
+        // compared values): what a last-place difference between two libms could turn (tools/campaign.py enforces a floor).  A value
+        // made of the host's numbers alone (-logNT - n log10 p: an exact 0 exists, w h = 6^4, p = 1/6, n = 10) is the reference's own.
+        if (fabs(v) <= 1.7976931348623157e308) {
+            if (!host_only) STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v) / c.logNT));       // (v is compared with 0: :1075, :242)
+            if (step > 0 && v != bestNFA)
+                STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA) / fmax(fmax(fabs(v), fabs(bestNFA)), c.logNT)));
+        }
         if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
         else if (v > bestNFA) { bestNFA = v; best = r; }
     }
@@ -1619,7 +1653,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         ws.cur_id = id_base; ws.gnum = 0; ws.has_copy = 0; ws.tm_pending = 0; ws.cache_epoch = -1; ws.members_cached = 0;
         ws.ex_upto = 0; ws.ex_sin = 0; ws.ex_cos = 0;
     }
-    c.logNT = g.logNT; c.lgamma = b.lgamma; c.ptab = b.ptab;
+    c.logNT = g.logNT; c.lgamma = b.lgamma; c.lg_count = b.lg_count; c.ptab = b.ptab;
     c.wslist = b.slist + (img * NW + wave) * (size_t)NS * b.gcap; c.gcap = b.gcap;
     if (threadIdx.x == 0) { g_par[0] = g.degThre; g_par[1] = g.regThre; g_par[2] = g.aliPro; g_par[3] = g.denThre; }
     if (lane == 0) g_ctx[wave] = c;                        // (c.lane is set by every reader)
@@ -2499,7 +2533,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
         if (lane == 0 && wave == 0 && !lds_ld(&s_abort)) { b.stats[img * kStatWords + 45] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15); b.stats[img * kStatWords + 46] = rt_begin; b.stats[img * kStatWords + 47] = (long long)__builtin_amdgcn_s_memrealtime(); }   // (developer record: when the image ran)
         if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth)); }
-        if (lane < ST_COUNT && !lds_ld(&s_abort) && (sslot(lane) != 11 || kStatSlots == ST_COUNT)) {
+        if (lane < ST_COUNT && !lds_ld(&s_abort) && (sslot(lane) != 11 || lane == ST_NFASLOW || kStatSlots == ST_COUNT)) {
             if (lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][sslot(lane)]);
             else atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
         }
@@ -2624,6 +2658,12 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             if (v != hprev) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + (size_t)hx * kStatWords) + lane, v - hprev);
             hprev = v;
         }
+        if (b.stats && lane == 0) {                        // ... and how close its NFA comparisons came to a tie
+            unsigned long long* const hs = reinterpret_cast<unsigned long long*>(b.stats + (size_t)hx * kStatWords);
+            atomicMax(&hs[ST_MINNFA], g_stat[c.wave][sslot(ST_MINNFA)]); atomicMax(&hs[ST_MINGAP], g_stat[c.wave][sslot(ST_MINGAP)]);
+            atomicAdd(&hs[ST_NFASLOW], g_stat[c.wave][sslot(ST_NFASLOW)]);
+        }
+        if (b.stats) { g_stat[c.wave][sslot(ST_MINNFA)] = 0ull; g_stat[c.wave][sslot(ST_MINGAP)] = 0ull; g_stat[c.wave][sslot(ST_NFASLOW)] = 0ull; }
         const EvalOut& eo = g_eo[wave];
         const bool skip = eo.skip != 0;
         const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;

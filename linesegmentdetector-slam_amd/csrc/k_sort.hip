@@ -6,10 +6,16 @@
 // (SURVEY 8a-Q4).  Here that order is produced directly by a stable counting sort:
 //
 //   one 1024-thread workgroup per image; wave s owns the s-th contiguous raster segment;
-//   pass 1  per-wave LDS histograms hist[s][pseBin - v]                     (LDS atomics)
+//   pass 1  streams magMap ONCE: bins, per-wave LDS histograms hist[s][pseBin - v] (LDS atomics), and the kept pixels
+//           (v != 0: one in ten on an occupancy map) compacted in raster order into the wave's own stretch of a scratch
+//           list (pixel, v) -- ballot + popcount, no global atomics;
 //   scan    start[s][b] = sum_{b'<b} tot[b'] + sum_{s'<s} hist[s'][b]        (block prefix sum)
-//   pass 2  each wave re-streams its segment 64 pixels at a time; lanes that share a bin get
-//           consecutive ranks in lane (= raster) order via ballot + popcount, no global atomics.
+//   pass 2  each wave walks ITS compacted list 64 kept pixels at a time (every lane busy).  The lanes of a chunk that share a
+//           bin find each other with one ballot per bit of the bin number (peers = AND over the bits of "ballot of the bit" or
+//           its complement) and take consecutive ranks in lane (= raster) order: one LDS read and one LDS write per chunk, no
+//           loop over the distinct bins.
+//   (Until round 5 pass 2 streamed magMap a second time and ranked the ~4.5 kept lanes of a raw 64-pixel chunk with a loop
+//    over their distinct bins: 1.5 ms per 512 maps and 2.4 x the algorithmic traffic.)
 //
 // The result is deterministic and independent of wave scheduling.
 #include "lsd_internal.h"
@@ -27,13 +33,16 @@ __device__ __forceinline__ int bin_of(double m, double zoom, int pseBin) {
 __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
                                               const unsigned long long* __restrict__ maxbits,
                                               uint32_t* __restrict__ ord, uint16_t* __restrict__ ordv,
-                                              int32_t* __restrict__ nb, int npx, int pseBin) {
+                                              int32_t* __restrict__ nb, uint32_t* __restrict__ kept_px, uint32_t* __restrict__ kept_v32,
+                                              int npx, int pseBin) {
     extern __shared__ uint32_t hist[];                             // [SWAVES][pseBin] then [SWAVES] scratch
     uint32_t* wsum = hist + SWAVES * pseBin;
     const size_t img = blockIdx.x;
     const double* m = mag + img * (size_t)npx;
     uint32_t* o = ord + img * (size_t)npx;
     uint16_t* ov = ordv + img * (size_t)npx;
+    uint32_t* kp = kept_px + img * (size_t)npx;                    // the kept pixels in raster order, wave s's from kp[beg_s] on
+    uint16_t* kv = reinterpret_cast<uint16_t*>(kept_v32 + img * (size_t)npx);   // ... and their bin values
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
     const double maxGrad = __longlong_as_double((long long)maxbits[img]);
@@ -49,7 +58,9 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     __syncthreads();
 
     uint32_t* myh = hist + wave * pseBin;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     constexpr int UN = 4;                                          // 64-pixel chunks per step: independent loads in flight per wave
+    int cnt = 0;                                                   // kept pixels of this wave so far (wave-uniform)
     for (int base = beg; base < end; base += 64 * UN) {
         double mv[UN];
         #pragma unroll
@@ -58,12 +69,19 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
             mv[j] = p < end ? m[p] : 0.0;
         }
         #pragma unroll
-        for (int j = 0; j < UN; j++) {
+        for (int j = 0; j < UN; j++) {                             // chunks in raster order
             const int v = bin_of(mv[j], zoom, pseBin);             // (0.0 gives bin 0)
-            if (v != 0) atomicAdd(&myh[pseBin - v], 1u);
+            const unsigned long long km = __ballot(v != 0);
+            if (v != 0) {
+                atomicAdd(&myh[pseBin - v], 1u);
+                const int k2 = beg + cnt + __builtin_popcountll(km & lt);
+                kp[k2] = (uint32_t)(base + 64 * j + lane);
+                kv[k2] = (uint16_t)v;
+            }
+            cnt += __builtin_popcountll(km);
         }
     }
-    __syncthreads();
+    __syncthreads();                                               // (also: this wave's own kept list is visible to it below)
 
     // exclusive scan over bins (descending value == ascending b), then over waves inside a bin
     {
@@ -90,33 +108,33 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     }
     __syncthreads();
 
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = beg; base < end; base += 64 * UN) {
-        double mv[UN];
+    const int nbits = 32 - __builtin_clz((unsigned)max(pseBin - 1, 1));   // bits of a bin number b = pseBin - v in [0, pseBin)
+    for (int base = 0; base < cnt; base += 64 * UN) {
+        uint32_t pv[UN];
+        int vv[UN];
         #pragma unroll
         for (int j = 0; j < UN; j++) {
-            const int p = base + 64 * j + lane;
-            mv[j] = p < end ? m[p] : 0.0;
+            const int k2 = base + 64 * j + lane;
+            pv[j] = 0u; vv[j] = pseBin;                            // (idle lanes: bin 0, kept apart from the others by the act mask)
+            if (k2 < cnt) { pv[j] = kp[beg + k2]; vv[j] = (int)kv[beg + k2]; }
         }
         #pragma unroll
         for (int j = 0; j < UN; j++) {                             // chunks in raster order
-            const int p = base + 64 * j + lane;
-            const int v = bin_of(mv[j], zoom, pseBin);
-            const int b = pseBin - v;
-            unsigned long long act = __ballot(v != 0);
-            while (act) {
-                const int l = __builtin_ctzll(act);
-                const int bsel = __builtin_amdgcn_readlane(b, l);
-                const bool mine = (v != 0) && (b == bsel);
-                const unsigned long long mm = __ballot(mine);
-                const uint32_t start = myh[bsel];
-                if (mine) {
-                    const uint32_t r = start + (uint32_t)__builtin_popcountll(mm & lt);
-                    o[r] = (uint32_t)p;
-                    ov[r] = (uint16_t)v;
-                }
-                if (lane == l) myh[bsel] = start + (uint32_t)__builtin_popcountll(mm);
-                act &= ~mm;
+            if (base + 64 * j >= cnt) break;                       // (wave-uniform)
+            const bool act = base + 64 * j + lane < cnt;
+            const int b = pseBin - vv[j];
+            unsigned long long peers = __ballot(act);              // lanes of this chunk with the same bin as this lane
+            for (int bit = 0; bit < nbits; bit++) {
+                const bool one = ((b >> bit) & 1) != 0;
+                const unsigned long long mk = __ballot(one);
+                peers &= one ? mk : ~mk;
+            }
+            const uint32_t start = myh[b];
+            if (act) {
+                const uint32_t r = start + (uint32_t)__builtin_popcountll(peers & lt);
+                o[r] = pv[j];
+                ov[r] = (uint16_t)vv[j];
+                if (((peers >> lane) >> 1) == 0ull) myh[b] = start + (uint32_t)__builtin_popcountll(peers);   // the group's last lane
             }
         }
     }
@@ -154,7 +172,8 @@ void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     // 16 x 1024 bins x 4 B is just over the 64 KiB default; gfx950 has 160 KiB of LDS per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(k_sort, dim3(n), dim3(SNT), lds, s, b.mag, b.maxbits, b.ord, b.ordv, b.nb, g.npx, g.pseBin);
+    // (the kept lists live in the region stage's seed arrays, which that stage fills at its start: they are free until then)
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(SNT), lds, s, b.mag, b.maxbits, b.ord, b.ordv, b.nb, b.seedidx, b.seedpos, g.npx, g.pseBin);
 }
 
 }  // namespace lsdhip

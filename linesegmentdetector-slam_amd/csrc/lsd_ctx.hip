@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,7 @@ struct lsd_ctx {
     bool hcap_lineim = false;
     // tables
     double *d_taps = nullptr, *d_lgamma = nullptr, *d_ptab = nullptr;
+    int lg_count = 0;                   // entries of d_lgamma
     lsd_params tab_params{};
     bool tab_valid = false;
     int tapR = 0;
@@ -88,6 +91,8 @@ struct lsd_ctx {
     int32_t* ga_cnt = nullptr;
     lsd_line* ga_slab = nullptr;
     size_t ga_cnt_cap = 0, ga_slab_cap = 0;
+    hipEvent_t ga_ev = nullptr;         // recorded behind the collectives of the last lsd_gather_lines (they read ga_cnt / ga_slab)
+    bool ga_ev_valid = false;
     // options
     int stop_after = 0;
     bool trace = false;
@@ -150,6 +155,18 @@ static double log_gamma_host(int x) {                               // LogGammaC
     return a + log(b);
 }
 
+// LogGammaCalculator(0 .. count - 1) from the host libm, computed once per process (a 2048 x 2048 map needs 377 k entries: ~40 ms)
+static std::mutex g_lg_mu;                                          // held while the table is grown and while a context copies out of it
+static const double* log_gamma_table(int count) {
+    static std::vector<double> tab;
+    if ((int)tab.size() < count) {
+        const int from = (int)tab.size();
+        tab.resize(count);
+        for (int i = from; i < count; i++) tab[i] = i >= 1 ? log_gamma_host(i) : 0.0;
+    }
+    return tab.data();
+}
+
 static int make_geom(const lsd_params* p, int cols, int rows, Geom* g) {
     if (!p || cols <= 0 || rows <= 0) return LSD_ERR_INVALID;
     if (!(p->sca > 0) || !(p->sig > 0) || !(p->angThre > 0) || p->pseBin < 1) return LSD_ERR_INVALID;
@@ -178,12 +195,21 @@ static int make_geom(const lsd_params* p, int cols, int rows, Geom* g) {
 }
 
 static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStream_t s) {
+    // log-gamma of every pixel count a rectangle of this geometry can have (all + 1 <= w*h + 1, myLSD.cpp:1030): host libm values, as
+    // the reference computes them; the device only looks them up
+    const int lg_need = (int)std::min<long long>(std::max<long long>((long long)g.npx + 2, kLgTable), kLgTableMax);
+    if (c->lg_count < lg_need) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->done_valid) HIPCHK(c, hipEventSynchronize(c->ev_done));
+        std::lock_guard<std::mutex> lk(g_lg_mu);
+        const double* tab = log_gamma_table(lg_need);
+        if (c->d_lgamma) { HIPCHK(c, hipFree(c->d_lgamma)); c->d_lgamma = nullptr; c->lg_count = 0; }
+        HIPCHK(c, hipMalloc(&c->d_lgamma, sizeof(double) * lg_need));
+        HIPCHK(c, hipMemcpy(c->d_lgamma, tab, sizeof(double) * lg_need, hipMemcpyHostToDevice));
+        c->lg_count = lg_need;
+    }
     if (c->tab_valid && memcmp(&c->tab_params, p, sizeof(lsd_params)) == 0) return LSD_OK;
-    if (!c->d_lgamma) {
-        std::vector<double> lg(kLgTable);
-        for (int i = 0; i < kLgTable; i++) lg[i] = i >= 1 ? log_gamma_host(i) : 0.0;
-        HIPCHK(c, hipMalloc(&c->d_lgamma, sizeof(double) * kLgTable));
-        HIPCHK(c, hipMemcpy(c->d_lgamma, lg.data(), sizeof(double) * kLgTable, hipMemcpyHostToDevice));
+    if (!c->d_ptab) {
         HIPCHK(c, hipMalloc(&c->d_ptab, sizeof(double) * kPTable * 3));
         HIPCHK(c, hipMalloc(&c->d_taps, sizeof(double) * 3 * (2 * kMaxTapRadius + 1)));
     }
@@ -227,8 +253,10 @@ static int waves_for(const lsd_ctx* c, int n) {
 
 // Workgroups that own no image and help from the start (k_region.hip): as many as the images leave workgroup slots of the device
 // free -- one 8-wave workgroup per CU, three 4-wave ones -- and the images' helper wavefronts (tun_help each) can use.
-static int pool_for(const lsd_ctx* c, int n) {
-    const int help = c->tun_help >= 0 ? c->tun_help : 24;
+constexpr int kPoolHelpMax = 64;        // helper wavefronts per image the pool is sized for at most (workspace: a wave slot each)
+static int pool_for(const lsd_ctx* c, int n, int help) {
+    if (help < 0) help = 24;
+    if (help > kPoolHelpMax) help = kPoolHelpMax;
     // Measured (tools/single_step_probe.py): the heaviest bench image alone 77.5 -> 30 ms, typical single images unchanged (they never
     // ask: tun_gate); a 64-image shard 49 -> 55 ms and the 512-image batch on 4 waves 87 -> 115 ms -- helpers that are there from the
     // start serve many images that merely look busy, and every remote evaluation costs its owner an export, a poll and a validation
@@ -241,13 +269,20 @@ static int pool_for(const lsd_ctx* c, int n) {
     const long long p = free_slots < want ? free_slots : want;
     return p > 0 ? (int)p : 0;
 }
+static int pool_for(const lsd_ctx* c, int n) { return pool_for(c, n, c->tun_help); }
+// ... and what the workspace is sized for: the pool of the default help setting even while help is switched off, so that switching
+// it on later (lsd_set_region_help) never makes the never-allocating entry point allocate
+static int pool_reserve_for(const lsd_ctx* c, int n) {
+    const int now = c->tun_help < 0 ? 24 : c->tun_help;
+    return pool_for(c, n, now > 24 ? now : 24);
+}
 
 // Words per wave of the member-mask array (4 per 8x8 tile) for any image of up to npx scaled pixels: tiles <= npx / 64 + (w + h) / 8 + 1,
 // and w, h <= 32766 (make_geom).
 static size_t tm_words(size_t npx) { return npx / 16 + 4 * 8200; }
 
 static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int max_lines, bool trace) {
-    const size_t need_ws = (n + (size_t)pool_for(c, (int)n)) * (size_t)waves_for(c, (int)n);   // per-wave arrays: wave slots of the images and of the helper pool
+    const size_t need_ws = (n + (size_t)pool_reserve_for(c, (int)n)) * (size_t)waves_for(c, (int)n);   // per-wave arrays: wave slots of the images and of the helper pool
     const bool grow_main = n > c->cap_n || npx > c->cap_npx || gpx > c->cap_gpx || need_ws > c->cap_ws;
     if (grow_main) {
         const size_t nn = n > c->cap_n ? n : c->cap_n, pp = npx > c->cap_npx ? npx : c->cap_npx;
@@ -312,6 +347,27 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int ma
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// The schedule settings of the region stage by name (see lsd_create / lsd_debug_set_tuning)
+struct Tuning { const char* name; int lo, hi; int lsd_ctx::*field; bool shipped; };
+static const Tuning kTunings[] = {
+    {"HELP", -1, 4096, &lsd_ctx::tun_help, true},          // helper wavefronts per image (as lsd_set_region_help)
+    {"POOL", 0, 16, &lsd_ctx::pool_max_images, true},      // calls with at most this many images get helper-only workgroups
+    {"SOFT", 0, 1 << 20, &lsd_ctx::tun_soft, false},       // look-ahead of the seed hand-out, shallow / deep end (seeds; 0: default)
+    {"CLAIM", 0, 1 << 20, &lsd_ctx::tun_claim, false},
+    {"FEED", 1, 8, &lsd_ctx::tun_feed, false},             // idle lane groups per refill
+    {"BIG", 0, 16, &lsd_ctx::tun_big, false},              // results a wave may have waiting for the cursor (0: default)
+    {"EARLY", 0, 4096, &lsd_ctx::tun_early, false},        // helpers before every workgroup has its CU (measured: a loss)
+    {"WB", 0, 100, &lsd_ctx::tun_wb, false},               // idle share (%) below which an image asks for help
+    {"GATE", 0, 1 << 22, &lsd_ctx::tun_gate, false},       // ... once it has been running for this long (x 1024 clocks)
+    {"SHARE", 0, 100, &lsd_ctx::tun_share, false},
+    {"UP", 0, 1 << 16, &lsd_ctx::tun_up, false},           // steps of the adaptive look-ahead
+    {"DOWN", 0, 1 << 16, &lsd_ctx::tun_down, false},
+    {"REQUEUE", 0, 1, &lsd_ctx::tun_requeue, false},       // 0: invalidated results are found at the cursor only
+    {"XPOLL", 100, 1 << 30, &lsd_ctx::tun_xpoll, false},   // clocks between two looks of a wave at the help protocol
+    {"LINGER", 1, 1 << 30, &lsd_ctx::tun_linger, false},   // looks (~27 us each) a helper takes for an image that asks before it gives its CU back
+    {"STOP", 0, 1 << 30, &lsd_ctx::tun_stop, false},       // developer build of the kernel: the seed loop ends after this many seeds (probe experiment)
+};
+
 extern "C" {
 
 int lsd_abi_version(void) { return LSD_ABI_VERSION; }
@@ -363,33 +419,22 @@ int lsd_create(lsd_ctx** out, int device) {
         if (hipHostMalloc((void**)&c->pin[k], kPinBytes, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { delete c; return LSD_ERR_NOMEM; }
     c->last_stream = c->stream;
-    {   // Schedule settings of the region stage from the environment (read once, here): none of them changes a result
-        // (tests/test_parity_gpu.py::test_schedule_of_the_region_stage_changes_nothing), each is clamped to the range the kernel
-        // assumes.  LSD_REGION_STOP (the seed loop cut short: it does change results) exists in the developer build only.
-        auto env_int = [](const char* name, int lo, int hi, int* out) {
-            const char* e = getenv(name);
-            if (!e || !*e) return;
-            char* end = nullptr;
-            const long v = strtol(e, &end, 10);
-            if (end == e) return;
-            *out = (int)(v < lo ? lo : v > hi ? hi : v);
-        };
-        env_int("LSD_REGION_SOFT", 0, 1 << 20, &c->tun_soft);        // look-ahead of the seed hand-out, shallow / deep end (seeds; 0: default)
-        env_int("LSD_REGION_CLAIM", 0, 1 << 20, &c->tun_claim);
-        env_int("LSD_REGION_FEED", 1, 8, &c->tun_feed);             // idle lane groups per refill
-        env_int("LSD_REGION_BIG", 0, 16, &c->tun_big);              // results a wave may have waiting for the cursor (0: default)
-        env_int("LSD_REGION_HELP", -1, 4096, &c->tun_help);         // helper wavefronts per image (as lsd_set_region_help)
-        env_int("LSD_REGION_EARLY", 0, 4096, &c->tun_early);        // helpers before every workgroup has its CU (measured: a loss)
-        env_int("LSD_REGION_WB", 0, 100, &c->tun_wb);               // idle share (%) below which an image asks for help
-        env_int("LSD_REGION_GATE", 0, 1 << 22, &c->tun_gate);       // ... once it has been running for this long (x 1024 clocks)
-        env_int("LSD_REGION_SHARE", 0, 100, &c->tun_share);
-        env_int("LSD_REGION_POOL", 0, 1 << 20, &c->pool_max_images); // calls with at most this many images get helper-only workgroups
-        env_int("LSD_REGION_UP", 0, 1 << 16, &c->tun_up);           // steps of the adaptive look-ahead
-        env_int("LSD_REGION_DOWN", 0, 1 << 16, &c->tun_down);
-        env_int("LSD_REGION_REQUEUE", 0, 1, &c->tun_requeue);       // 0: invalidated results are found at the cursor only
-        env_int("LSD_REGION_XPOLL", 100, 1 << 30, &c->tun_xpoll);   // clocks between two looks of a wave at the help protocol
-        env_int("LSD_REGION_LINGER", 1, 1 << 30, &c->tun_linger);   // looks (~27 us each) a helper takes for an image that asks before it gives its CU back
-        env_int("LSD_REGION_STOP", 0, 1 << 30, &c->tun_stop);       // developer build: the seed loop ends after this many seeds (probe experiment)
+    // Schedule settings of the region stage.  The shipped library reads two from the environment, once, here: LSD_REGION_HELP (as
+    // lsd_set_region_help) and LSD_REGION_POOL (calls with at most this many images get helper-only workgroups).  The others are
+    // developer settings: lsd_debug_set_tuning() by name, and -- in the developer builds only (make stats / exp: -DLSD_DEVELOPER_KNOBS)
+    // -- LSD_REGION_<NAME> from the environment.  None changes a result (tests/test_parity_gpu.py::
+    // test_schedule_of_the_region_stage_changes_nothing); every value is clamped to the range the kernel assumes.
+    for (const Tuning& t : kTunings) {
+#ifndef LSD_DEVELOPER_KNOBS
+        if (!t.shipped) continue;
+#endif
+        const std::string name = std::string("LSD_REGION_") + t.name;
+        const char* e = getenv(name.c_str());
+        if (!e || !*e) continue;
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end == e) continue;
+        c->*(t.field) = (int)(v < t.lo ? t.lo : v > t.hi ? t.hi : v);
     }
     *out = c;
     return LSD_OK;
@@ -405,6 +450,7 @@ void lsd_destroy(lsd_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->ga_ev) (void)hipEventDestroy(c->ga_ev);
     for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_flat) (void)hipFree(c->h_flat);
@@ -431,6 +477,16 @@ int lsd_set_region_help(lsd_ctx* c, int waves) {
     if (!c || waves < -1 || waves > 4096) return LSD_ERR_INVALID;
     c->tun_help = waves;
     return LSD_OK;
+}
+
+int lsd_debug_set_tuning(lsd_ctx* c, const char* name, int value) {
+    if (!c || !name) return LSD_ERR_INVALID;
+    for (const Tuning& t : kTunings)
+        if (strcmp(name, t.name) == 0) {
+            c->*(t.field) = value < t.lo ? t.lo : value > t.hi ? t.hi : value;
+            return LSD_OK;
+        }
+    return LSD_ERR_INVALID;
 }
 
 int lsd_debug_set_stamp_budget(lsd_ctx* c, unsigned grows) {
@@ -493,7 +549,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
         b.npool = b.xq ? pool_for(c, n) : 0;
     }
-    b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.ptab = c->d_ptab;
+    b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.lg_count = c->lg_count; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
 
     HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));
@@ -956,6 +1012,8 @@ int lsd_gather_lines(lsd_ctx* c, const lsd_comm* comm, const lsd_line* d_lines, 
         HIPCHK(c, re_alloc(&c->ga_slab, (size_t)cap_rows));
         c->ga_slab_cap = (size_t)cap_rows;
     }
+    // the staging buffers belong to the context: an earlier hand-off's collectives (on whatever stream) must have read them
+    if (c->ga_ev_valid) HIPCHK(c, hipStreamWaitEvent(s, c->ga_ev, 0));
     // rows past this rank's lines are zero (nothing stale travels)
     HIPCHK(c, hipMemsetAsync(c->ga_slab, 0, sizeof(lsd_line) * (size_t)cap_rows, s));
     launch_pack_lines(d_lines, d_counts, n_local, max_lines, per, cap_rows, c->ga_cnt, c->ga_cnt + (per + 2), c->ga_slab, s);
@@ -965,6 +1023,9 @@ int lsd_gather_lines(lsd_ctx* c, const lsd_comm* comm, const lsd_line* d_lines, 
         c->err = "lsd_gather_lines: the communicator's all_gather failed";
         return LSD_ERR_HIP;
     }
+    if (!c->ga_ev) HIPCHK(c, hipEventCreateWithFlags(&c->ga_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ga_ev, s));
+    c->ga_ev_valid = true;
     c->last_stream = s;
     return LSD_OK;
 }
@@ -981,7 +1042,7 @@ int lsd_debug_calibrate(lsd_ctx* c, size_t bytes) {
 }
 
 int lsd_debug_eval_math(lsd_ctx* c, int fn, const double* a, const double* b, double* out0, double* out1, size_t n) {
-    if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 3 || (fn == 1 && !b)) return LSD_ERR_INVALID;
+    if (!c || !a || !out0 || !out1 || n == 0 || fn < 0 || fn > 6 || ((fn == 1 || fn == 6) && !b)) return LSD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
     HIPCHK(c, hipMalloc(&da, n * 8)); HIPCHK(c, hipMalloc(&db, n * 8)); HIPCHK(c, hipMalloc(&d0, n * 8)); HIPCHK(c, hipMalloc(&d1, n * 8));

@@ -9,7 +9,13 @@
 // three-field communicator (rank, world, all_gather callback): lsd_comm_from_rccl binds it to ncclAllGather of an RCCL
 // communicator (RCCL over xGMI on MI355X); tests bind it to a copy loop.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+// (only three RCCL entry points are used, through dlsym: their prototypes are restated here so that the library builds -- and loads --
+//  without the RCCL headers and library)
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;            // ncclSuccess == 0
+typedef int ncclDataType_t;          // ncclInt8 == 0
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclInt8 = 0;
 
 #include <string.h>
 
@@ -19,8 +25,9 @@
 
 namespace lsdhip {
 
-// cpad[per + 2]: counts of this rank's images clamped to max_lines (zero-padded to `per`), [per] = rows in the slab, [per + 1] = 1 if
-// rows were dropped (more than cap_rows lines, or an image with more than max_lines): one workgroup, n_local <= a few thousand
+// cpad[per + 2]: counts of this rank's images clamped to max_lines (zero-padded to `per`), [per] = rows in the slab, [per + 1] = flags:
+// bit 0 rows were dropped (more than cap_rows lines, or an image with more than max_lines), bit 1 an image the region stage gave up
+// (count < 0: the watchdog).  One workgroup, n_local <= a few thousand
 __global__ __launch_bounds__(256) void k_pack_counts(const int32_t* __restrict__ counts, int n_local, int max_lines, int per, int cap_rows,
                                                      int32_t* __restrict__ cpad, int32_t* __restrict__ offs) {
     __shared__ int s_part[256];
@@ -28,13 +35,13 @@ __global__ __launch_bounds__(256) void k_pack_counts(const int32_t* __restrict__
     const int t = threadIdx.x;
     const int chunk = (n_local + 255) / 256, lo = min(t * chunk, n_local), hi = min(lo + chunk, n_local);
     int sum = 0, over = 0;
-    for (int i = lo; i < hi; i++) { const int c = counts[i]; sum += max(0, min(c, max_lines)); over |= (c > max_lines || c < 0) ? 1 : 0; }
+    for (int i = lo; i < hi; i++) { const int c = counts[i]; sum += max(0, min(c, max_lines)); over |= (c > max_lines ? 1 : 0) | (c < 0 ? 2 : 0); }
     s_part[t] = sum; s_over[t] = over;
     __syncthreads();
     if (t == 0) {
         int run = 0, ov = 0;
         for (int j = 0; j < 256; j++) { const int v = s_part[j]; s_part[j] = run; run += v; ov |= s_over[j]; }
-        cpad[per] = min(run, cap_rows); cpad[per + 1] = (ov || run > cap_rows) ? 1 : 0;
+        cpad[per] = min(run, cap_rows); cpad[per + 1] = ov | (run > cap_rows ? 1 : 0);
     }
     __syncthreads();
     int run = s_part[t];
@@ -75,16 +82,18 @@ int lsd_gather_layout(int n_total, int world, int* per_rank, size_t* counts_word
     return LSD_OK;
 }
 
-// ---- RCCL binding: the symbols are looked up at run time, in the process first (a host that links or has loaded RCCL -- the library
-//      whose communicator it hands in) and in librccl.so.1 otherwise, so that liblsdhip.so itself loads without RCCL ----
+// ---- RCCL binding: the symbols are looked up at run time in the RCCL the PROCESS has loaded -- the library the communicator handed in
+//      belongs to -- so that liblsdhip.so itself loads without RCCL.  A second copy is never loaded: a communicator must not be passed
+//      to another instance of the library than the one that made it (LSD_ERR_UNSUPPORTED instead) ----
 typedef ncclResult_t (*all_gather_fn)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*comm_int_fn)(const ncclComm_t, int*);
 static void* rccl_sym(const char* name) {
-    void* p = dlsym(RTLD_DEFAULT, name);
+    void* p = dlsym(RTLD_DEFAULT, name);                 // linked by the host, or loaded with RTLD_GLOBAL
     if (p) return p;
+    // loaded privately (RTLD_LOCAL, e.g. by a Python extension): take a handle to that very copy, do not load one
     static void* h = nullptr;
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     return h ? dlsym(h, name) : nullptr;
 }
 static int rccl_all_gather(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream) {
@@ -109,12 +118,12 @@ int lsd_gather_unpack(const int32_t* counts_all, const lsd_line* slabs_all, int 
     int per = 0;
     lsd_gather_layout(n_total, world, &per, nullptr);
     size_t total = 0;
-    bool over = false;
+    int flags = 0;
     for (int r = 0; r < world; r++) {
         const int32_t* c = counts_all + (size_t)r * (per + 2);
         int lo, hi;
         lsd_shard_range(n_total, world, r, &lo, &hi);
-        if (c[per + 1]) over = true;
+        flags |= c[per + 1];
         size_t row = 0;
         for (int i = lo; i < hi; i++) {
             offsets_out[i] = (int32_t)total;
@@ -128,7 +137,8 @@ int lsd_gather_unpack(const int32_t* counts_all, const lsd_line* slabs_all, int 
         }
     }
     offsets_out[n_total] = (int32_t)total;
-    return over ? LSD_ERR_CAPACITY : LSD_OK;
+    // (either way offsets and lines hold every record that did arrive)
+    return (flags & 2) ? LSD_ERR_INTERNAL : (flags & 1) ? LSD_ERR_CAPACITY : LSD_OK;
 }
 
 }  // extern "C"

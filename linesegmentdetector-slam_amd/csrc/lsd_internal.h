@@ -8,7 +8,8 @@ namespace lsdhip {
 
 constexpr double kPi = 3.14159265358979323846;  // == 4.0*atan(1.0), myLSD.cpp:9
 constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per phase kernel
-constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries
+constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries every context starts with; it grows to w*h + 2 (the largest
+constexpr int kLgTableMax = 1 << 23;            //    pixel count a rectangle can have, + 1), up to this many
 constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
 // Help across workgroups in the region stage (k_region.hip): a control block of 32-bit words per launch, cleared before it.
@@ -95,7 +96,8 @@ struct Buffers {
     int max_lines;
     // tables
     const double* taps;    // 3 x (2*tapR+1)
-    const double* lgamma;  // kLgTable
+    const double* lgamma;  // lg_count entries: LogGammaCalculator(i) from the host libm
+    int lg_count;
     const double* ptab;    // kPTable x 3 : log(p), log10(p), log(1-p)
     // debug
     void* seeds;           // n x npx trace records or null

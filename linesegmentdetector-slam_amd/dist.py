@@ -26,7 +26,7 @@ def shard_range(n_items, world, rank):
 def compact_lines(lines_i64, counts):
     """[n, max_lines, 10] int64 + [n] int32 -> dense [sum(min(count,max_lines)), 10] int64 (image-major)."""
     n, max_lines, _ = lines_i64.shape
-    c = counts.clamp(max=max_lines).to(torch.int64)
+    c = counts.clamp(min=0, max=max_lines).to(torch.int64)          # (-1: an image the region stage gave up -- no lines)
     mask = torch.arange(max_lines, device=lines_i64.device)[None, :] < c[:, None]
     return lines_i64[mask], c
 
@@ -36,14 +36,14 @@ def pack_lines(lines_i64, counts, cap_rows):
     c int64[n], overflow bool[1]) -- all on the device, no host synchronisation (rows that do not fit go to a dump row)."""
     n, max_lines, _ = lines_i64.shape
     dev = lines_i64.device
-    c = counts.clamp(max=max_lines).to(torch.int64)
+    c = counts.clamp(min=0, max=max_lines).to(torch.int64)          # (-1: an image the region stage gave up -- no lines, flagged below)
     off = torch.cumsum(c, 0) - c
     k = torch.arange(max_lines, device=dev)[None, :]
     dest = off[:, None] + k
     dest = torch.where((k < c[:, None]) & (dest < cap_rows), dest, torch.full_like(dest, cap_rows))
     payload = torch.zeros((cap_rows + 1, WORDS_PER_LINE), dtype=torch.int64, device=dev)
     payload[dest.reshape(-1)] = lines_i64.reshape(-1, WORDS_PER_LINE)
-    return payload[:cap_rows], c, (c.sum() > cap_rows).reshape(1)
+    return payload[:cap_rows], c, ((c.sum() > cap_rows) | (counts < 0).any() | (counts > max_lines).any()).reshape(1)
 
 
 def gather_line_lists(lines_i64, counts, n_total, dst=0, group=None, cap_rows=None, dense=True):

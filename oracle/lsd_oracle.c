@@ -10,6 +10,7 @@
  * baseline (no FMA), glibc libm -- the reference's floating-point environment (Q12).
  */
 #include "lsd_oracle.h"
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -117,6 +118,7 @@ typedef struct {
     int *gx, *gy;      /* grow-order copy (never reordered) for the marking loops */
     int gnum;
     double logNT;
+    int nfa_host_only; /* (debug counters) the last NFA value was -logNT [- n log10 p]: no exp / log10 / pow of the tail behind it */
     orc_debug *dbg;
 } orc_state;
 
@@ -338,6 +340,15 @@ double orc_log_gamma(int x)
     return a + log(b);
 }
 
+/* The libm calls of RectangleNFACalculator that the HIP path evaluates ON THE DEVICE (everything else on this page the host
+ * computes with its libm and hands over as tables): plain libm here; the diagnostic build liblsd_oracle_cr.so (cr_shim.h)
+ * replaces them by correctly rounded ones. */
+#ifndef NFA_EXP
+#define NFA_EXP exp
+#define NFA_LOG10 log10
+#define NFA_POW pow
+#endif
+
 /* a12: RectangleNFACalculator, myLSD.cpp:926-1059.
  * The full-image "deg > pi -> -= pi" pass (:940-945) is a no-op (atan2 <= pi and values within
  * 1e-6 of pi were zeroed at :170-171) and is not restated. */
@@ -346,6 +357,7 @@ static double rectangle_nfa(orc_state *st, const orc_rec *rec)
     const int xLim = st->w, yLim = st->h;
     const double logNT = st->logNT;
     if (st->dbg) st->dbg->nfa_calls++;
+    st->nfa_host_only = 1;
     double verX[4], verY[4], vx[4], vy[4];
     verX[0] = rec->x1 - rec->dy * rec->wid / 2.0;                      /* :949-956 */
     verX[1] = rec->x2 - rec->dy * rec->wid / 2.0;
@@ -395,12 +407,13 @@ static double rectangle_nfa(orc_state *st, const orc_rec *rec)
     double log1Coef = orc_log_gamma(allPixNum + 1) - orc_log_gamma(aliPixNum + 1)
                     - orc_log_gamma(allPixNum - aliPixNum + 1);        /* :1029-1030 */
     double log1Term = log1Coef + aliPixNum * log(rec->p) + (allPixNum - aliPixNum) * log(1 - rec->p);
-    double term = exp(log1Term);
+    double term = NFA_EXP(log1Term);
     double eps = 2.2204e-16;
     if (fabs(term) < 100 * eps) {                                      /* :1037-1043 */
-        if (aliPixNum > allPixNum * rec->p) return -log10(term) - logNT;
+        if (aliPixNum > allPixNum * rec->p) { st->nfa_host_only = 0; return -NFA_LOG10(term) - logNT; }
         return -logNT;
     }
+    st->nfa_host_only = 0;
     double binTail = term, tole = 0.1;
     for (int i = aliPixNum + 1; i <= allPixNum; i++) {                 /* :1046-1056 */
         double binTerm = (allPixNum - i + 1) / (i * 1.0);
@@ -408,11 +421,25 @@ static double rectangle_nfa(orc_state *st, const orc_rec *rec)
         term *= multTerm;
         binTail += term;
         if (binTerm < 1) {
-            double err = term * ((1 - pow(multTerm, allPixNum - i + 1)) / (1.0 - multTerm) - 1);
-            if (err < tole * fabs(-log10(binTail) - logNT) * binTail) break;
+            double err = term * ((1 - NFA_POW(multTerm, allPixNum - i + 1)) / (1.0 - multTerm) - 1);
+            if (err < tole * fabs(-NFA_LOG10(binTail) - logNT) * binTail) break;
         }
     }
-    return -log10(binTail) - logNT;
+    return -NFA_LOG10(binTail) - logNT;
+}
+
+/* (debug counters only) a candidate v is about to be compared with 0 and, unless it is the first, with the best so far */
+static double note_nfa(orc_state *st, double v, double best, int first)
+{
+    if (st->dbg && fabs(v) <= DBL_MAX) {
+        const double a = fabs(v) / st->logNT;
+        if (!st->nfa_host_only && a < st->dbg->nfa_min_abs) st->dbg->nfa_min_abs = a;   /* (-logNT - n log10 p: host numbers on the HIP path too) */
+        if (!first && v != best) {
+            const double g = fabs(v - best) / fmax(fmax(fabs(v), fabs(best)), st->logNT);
+            if (g < st->dbg->nfa_min_gap) st->dbg->nfa_min_gap = g;
+        }
+    }
+    return v;
 }
 
 /* a14: RectangleImprover, myLSD.cpp:1061-1158 */
@@ -420,12 +447,12 @@ static double rectangle_improver(orc_state *st, orc_rec *rec_io)
 {
     const double delt = 0.5, delt2 = delt / 2.0;
     orc_rec best = *rec_io;
-    double bestNFA = rectangle_nfa(st, &best);
+    double bestNFA = note_nfa(st, rectangle_nfa(st, &best), 0, 1);
     if (bestNFA > 0) return bestNFA;
     orc_rec r = best;
     for (int i = 0; i < 5; i++) {                                      /* :1084-1092 */
         r.p /= 2.0; r.prec = r.p * PI;
-        double v = rectangle_nfa(st, &r);
+        double v = note_nfa(st, rectangle_nfa(st, &r), bestNFA, 0);
         if (v > bestNFA) { bestNFA = v; best = r; }
     }
     if (bestNFA > 0) { *rec_io = best; return bestNFA; }
@@ -433,7 +460,7 @@ static double rectangle_improver(orc_state *st, orc_rec *rec_io)
     for (int i = 0; i < 5; i++) {                                      /* :1097-1107 */
         if (r.wid - delt >= 0.5) {
             r.wid -= delt;
-            double v = rectangle_nfa(st, &r);
+            double v = note_nfa(st, rectangle_nfa(st, &r), bestNFA, 0);
             if (v > bestNFA) { bestNFA = v; best = r; }
         }
     }
@@ -444,7 +471,7 @@ static double rectangle_improver(orc_state *st, orc_rec *rec_io)
             r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2;
             r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2;
             r.wid -= delt;
-            double v = rectangle_nfa(st, &r);
+            double v = note_nfa(st, rectangle_nfa(st, &r), bestNFA, 0);
             if (v > bestNFA) { bestNFA = v; best = r; }
         }
     }
@@ -455,7 +482,7 @@ static double rectangle_improver(orc_state *st, orc_rec *rec_io)
             r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2;
             r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2;
             r.wid -= delt;
-            double v = rectangle_nfa(st, &r);
+            double v = note_nfa(st, rectangle_nfa(st, &r), bestNFA, 0);
             if (v > bestNFA) { bestNFA = v; best = r; }
         }
     }
@@ -463,7 +490,7 @@ static double rectangle_improver(orc_state *st, orc_rec *rec_io)
     r = best;
     for (int i = 0; i < 5; i++) {                                      /* :1148-1156 */
         r.p /= 2.0; r.prec = r.p * PI;
-        double v = rectangle_nfa(st, &r);
+        double v = note_nfa(st, rectangle_nfa(st, &r), bestNFA, 0);
         if (v > bestNFA) { bestNFA = v; best = r; }
     }
     *rec_io = best;
@@ -522,7 +549,7 @@ int orc_lsd(uint8_t *map, int cols, int rows, size_t stride,
             uint8_t *lineIm, orc_line **lines, int *n, orc_debug *dbg)
 {
     if (!map || cols <= 0 || rows <= 0 || !lines || !n) return -1;
-    if (dbg) memset(dbg, 0, sizeof(*dbg));
+    if (dbg) { memset(dbg, 0, sizeof(*dbg)); dbg->nfa_min_abs = HUGE_VAL; dbg->nfa_min_gap = HUGE_VAL; }
     const int w = cvt_int(floor(cols * sca));                          /* :132 */
     const int h = cvt_int(floor(rows * sca));                          /* :133 */
     if (w < 2 || h < 2) { *lines = NULL; *n = 0; return 0; }

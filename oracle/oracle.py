@@ -43,7 +43,7 @@ class OrcDebug(C.Structure):
                 ("recs", C.POINTER(C.c_double)),
                 ("grow_calls", C.c_long), ("grown_px", C.c_long), ("nfa_calls", C.c_long),
                 ("rrr_calls", C.c_long), ("rrr_passes", C.c_long), ("rrr_sentinel_drops", C.c_long),
-                ("rrr_oob_reads", C.c_long)]
+                ("rrr_oob_reads", C.c_long), ("nfa_min_abs", C.c_double), ("nfa_min_gap", C.c_double)]
 
 
 def build(asan=False):
@@ -137,7 +137,7 @@ def lsd(map_u8, sca=0.3, sig=0.6, angThre=22.5, denThre=0.7, pseBin=1024, want_l
             d["seeds"] = seeds
             d["recs"] = _arr(dbg.recs, 12 * n.value, np.float64).reshape(n.value, 12)
         for k in ("grow_calls", "grown_px", "nfa_calls", "rrr_calls", "rrr_passes", "rrr_sentinel_drops",
-                  "rrr_oob_reads"):
+                  "rrr_oob_reads", "nfa_min_abs", "nfa_min_gap"):
             d[k] = getattr(dbg, k)
         L.orc_debug_free(C.byref(dbg))
         out["dbg"] = d

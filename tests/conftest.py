@@ -11,7 +11,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # one hardware queue per batch in flight (bench.py's throughput mode; read when HIP initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")         # bench.py's setting (one hardware queue per batch in flight and to spare; read when HIP initialises)
 
 
 def pytest_configure(config):

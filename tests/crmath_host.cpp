@@ -55,6 +55,51 @@ void crm_atan2_fast_raw_n(const double* y, const double* x, double* out, long n)
         out[3 * i + 1] = raw.hi; out[3 * i + 2] = raw.lo;
     }
 }
+void crm_exp_n(const double* x, double* o, long n) { for (long i = 0; i < n; i++) o[i] = crm::exp_cr(x[i]); }
+void crm_log_n(const double* x, double* o, long n) { for (long i = 0; i < n; i++) o[i] = crm::log_cr(x[i]); }
+void crm_log10_n(const double* x, double* o, long n) { for (long i = 0; i < n; i++) o[i] = crm::log10_cr(x[i]); }
+void crm_pow_n(const double* x, const double* y, double* o, long n) { for (long i = 0; i < n; i++) o[i] = crm::pow_cr(x[i], y[i]); }
+// first stages against the full evaluations (as for sincos / atan2 above)
+long crm_exp_fast_n(const double* x, long n, long* bad) {
+    long acc = 0; *bad = 0;
+    for (long i = 0; i < n; i++) {
+        double r;
+        if (!crm::exp_fast(x[i], r)) continue;
+        acc++;
+        const double r2 = crm::exp_cr(x[i]);
+        if (__builtin_memcmp(&r, &r2, 8)) ++*bad;
+    }
+    return acc;
+}
+long crm_log10_fast_n(const double* x, long n, long* bad) {
+    long acc = 0; *bad = 0;
+    for (long i = 0; i < n; i++) {
+        double r;
+        if (!crm::log10_fast(x[i], r)) continue;
+        acc++;
+        const double r2 = crm::log10_cr(x[i]);
+        if (__builtin_memcmp(&r, &r2, 8)) ++*bad;
+    }
+    return acc;
+}
+// the unrounded first-stage values: out[4*i..] = answered, hi, lo, error bound (exp: the bound is |hi| 2^-70, the value is the mantissa part)
+void crm_exp_fast_raw_n(const double* x, double* out, long n) {
+    for (long i = 0; i < n; i++) {
+        double r; crm::dd raw = {0, 0};
+        out[4 * i] = crm::exp_fast(x[i], r, &raw) ? 1.0 : 0.0;
+        out[4 * i + 1] = raw.hi; out[4 * i + 2] = raw.lo; out[4 * i + 3] = fabs(raw.hi) * 0x1p-70;
+    }
+}
+void crm_log10_fast_raw_n(const double* x, double* out, long n) {
+    for (long i = 0; i < n; i++) {
+        double r, e = 0; crm::dd raw = {0, 0};
+        out[4 * i] = crm::log10_fast(x[i], r, &raw, &e) ? 1.0 : 0.0;
+        out[4 * i + 1] = raw.hi; out[4 * i + 2] = raw.lo; out[4 * i + 3] = e;
+    }
+}
+void libm_exp_n(const double* x, double* o, long n) { for (long i = 0; i < n; i++) o[i] = exp(x[i]); }
+void libm_log10_n(const double* x, double* o, long n) { for (long i = 0; i < n; i++) o[i] = log10(x[i]); }
+void libm_pow_n(const double* x, const double* y, double* o, long n) { for (long i = 0; i < n; i++) o[i] = pow(x[i], y[i]); }
 void libm_sincos_n(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) { s[i] = sin(x[i]); c[i] = cos(x[i]); } }
 void libm_atan2_n(const double* y, const double* x, double* out, long n) { for (long i = 0; i < n; i++) out[i] = atan2(y[i], x[i]); }
 void libm_atan_n(const double* v, double* out, long n) { for (long i = 0; i < n; i++) out[i] = atan(v[i]); }

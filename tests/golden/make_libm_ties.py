@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/libm_ties.npz: the images of the random parity campaigns (tools/campaign.py, 60 000 images + 1 800 large ones,
+profiles/r04u_campaign_*.log) on which the HIP path and the glibc-built oracle disagree by one accept / reject decision.  On every
+one of them glibc misrounds a sin / cos / atan2 by one ulp on a structural tie (a rectangle edge exactly on a pixel row); the HIP
+path evaluates those functions correctly rounded and equals the restatement rebuilt on correctly rounded functions
+(oracle/liblsd_oracle_cr.so) bit for bit.  The images are pure functions of their campaign number (tools/campaign_images.py).
+Also writes libm_ties.json: per image the parameters, the line counts of the two builds and in how many usedMap / lineIm pixels they differ
+(what tests/test_oracle.py holds the two oracle builds to)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from campaign_images import campaign_image  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+SMALL = [2995, 1759, 6382, 10647, 18262, 27264, 38359, 40212, 45813, 48150, 54902, 55115, 56831, 58631]
+BIG = [297]
+NAMES = {2995: "tie_a", 1759: "tie_b"}                     # (the two fixtures of round 3 keep their names)
+
+out, table = {}, {}
+for i, big in [(i, False) for i in SMALL] + [(i, True) for i in BIG]:
+    img, kw, _ = campaign_image(i, big)
+    name = NAMES.get(i, "%s%d" % ("big" if big else "img", i))
+    a = oracle.lsd(img.copy(), debug=True, **kw)
+    b = oracle.lsd(img.copy(), debug=True, _lib=oracle.lib_cr(), **kw)
+    out[name] = img
+    table[name] = (kw, len(a["lines"]), len(b["lines"]), int((a["dbg"]["used"] != b["dbg"]["used"]).sum()),
+                   int((a["lineIm"] != b["lineIm"]).sum()))
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "libm_ties.npz"), **out)
+json.dump({k: dict(params=v[0], lines_glibc=v[1], lines_cr=v[2], used_diff=v[3], lineim_diff=v[4]) for k, v in table.items()},
+          open(os.path.join(ROOT, "tests", "golden", "libm_ties.json"), "w"), indent=1)
+for k, v in table.items():
+    print(k, v)

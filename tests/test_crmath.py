@@ -85,6 +85,127 @@ def test_glibc_differs_only_by_its_own_misroundings(crm):
     assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+def _rn(mp, v):
+    """an mpf rounded to the nearest double, ties to even, subnormal results and overflow included (float() of an mpf does not
+    promise the single rounding below 2^-1022)"""
+    import math
+    if v == 0:
+        return 0.0
+    sgn = -1 if v < 0 else 1
+    v = abs(v)
+    e = int(mp.floor(mp.log(v, 2)))
+    while mp.ldexp(1, e) > v:
+        e -= 1
+    while mp.ldexp(1, e + 1) <= v:
+        e += 1
+    q = max(e, -1022) - 52                                       # exponent of the unit in the last place
+    t = mp.ldexp(v, -q)
+    n = int(mp.floor(t))
+    f = t - n
+    if f > mp.mpf(1) / 2 or (f == mp.mpf(1) / 2 and n % 2 == 1):
+        n += 1
+    try:
+        return sgn * math.ldexp(n, q)
+    except OverflowError:
+        return sgn * math.inf
+
+
+def explog_samples(n):
+    import math
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-746, 710, n), rng.uniform(-745.2, -707, n // 4), rng.uniform(-1, 1, n // 4) * 10.0 ** rng.uniform(-20, 0, n // 4),
+                         np.array([0.0, -0.0, 709.782712893384, 709.7827128933841, -745.1332191019411, -745.1332191019412, -744.44,
+                                   -708.3964185322641, 1e-320, -1e-320, 1.0, -1.0]),
+                         np.arange(-1075, 1025) * math.log(2), rng.integers(-68000, 65000, n // 4) * (math.log(2) / 64)])
+    xl = np.concatenate([10.0 ** rng.uniform(-323, 308, n), rng.uniform(0.5, 2, n), 1 + rng.normal(0, 1, n // 4) * 10.0 ** rng.uniform(-16, -1, n // 4),
+                         10.0 ** rng.integers(-300, 300, 600).astype(float),
+                         np.array([1.0, 2.0, 0.5, 10.0, 1e-310, 5e-324, 1.7976931348623157e308, math.sqrt(2), 1.4140625, 1.4139, 1.9921875, 1.99218749]),
+                         1 + np.arange(0, 129) / 128.0, (1 + np.arange(0, 129) / 128.0) * (1 - 2.0 ** -52)])
+    xl = np.abs(xl)
+    xl = xl[xl > 0]
+    # pow as the NFA calls it: a ratio in (0, 1) to a pixel count (myLSD.cpp:1052); and ordinary arguments
+    px = np.concatenate([rng.uniform(0, 1, n), 1 - 10.0 ** rng.uniform(-12, 0, n // 2), rng.uniform(0.01, 30, n // 2), np.array([0.5, 0.25, 2.0, 1.0, 0.999999, 1e-300])])
+    py = np.concatenate([rng.integers(1, 6000, n).astype(float), rng.integers(1, 100000, n // 2).astype(float), rng.uniform(-50, 50, n // 2),
+                         np.array([3.0, 1074.0, 1023.0, 55.0, 1e7, 3.0])])
+    return xs, xl, px, py
+
+
+def test_exp_log_pow_are_correctly_rounded(crm):
+    """exp / log / log10 / pow of crmath.h (RectangleNFACalculator's libm calls on the device) against mpmath: the correctly rounded
+    double every time, subnormal results included; and how often glibc itself is not (its log10 in one call out of seven)."""
+    import mpmath as mp
+    mp.mp.prec = 500
+    xs, xl, px, py = explog_samples(3000)
+    o = np.zeros(len(xs))
+    crm.crm_exp_n(P(xs), P(o), C.c_long(len(xs)))
+    e = np.array([_rn(mp, mp.exp(mp.mpf(float(x)))) for x in xs])
+    assert np.array_equal(o, e)
+    g = np.zeros(len(xs))
+    crm.libm_exp_n(P(xs), P(g), C.c_long(len(xs)))
+    assert np.abs(g.view(np.int64) - e.view(np.int64)).max() <= 1 and (g != e).mean() < 0.01
+    for fn, mf in ((crm.crm_log_n, mp.log), (crm.crm_log10_n, mp.log10)):
+        o = np.zeros(len(xl))
+        fn(P(xl), P(o), C.c_long(len(xl)))
+        e = np.array([_rn(mp, mf(mp.mpf(float(x)))) for x in xl])
+        assert np.array_equal(o, e)
+    g = np.zeros(len(xl))
+    crm.libm_log10_n(P(xl), P(g), C.c_long(len(xl)))
+    assert np.abs(g.view(np.int64) - e.view(np.int64)).max() <= 2 and (g != e).mean() < 0.3
+    o = np.zeros(len(px))
+    crm.crm_pow_n(P(px), P(py), P(o), C.c_long(len(px)))
+    e = np.array([_rn(mp, mp.power(mp.mpf(float(a)), mp.mpf(float(b)))) for a, b in zip(px, py)])
+    assert np.array_equal(o, e)
+    g = np.zeros(len(px))
+    crm.libm_pow_n(P(px), P(py), P(g), C.c_long(len(px)))
+    fin = np.isfinite(e) & (e > 0)
+    assert np.abs(g[fin].view(np.int64) - e[fin].view(np.int64)).max() <= 1 and (g != e).mean() < 0.01
+
+
+def test_exp_log10_first_stages(crm):
+    """exp_fast / log10_fast (what RectangleNFACalculator's two value-carrying calls run first): every answer equals the double-double
+    evaluation bit for bit, nearly every call is answered, and the unrounded values stay within a quarter (exp) / half (log10: 0.2
+    measured) of the error bound the rounding test assumes."""
+    import math
+    import mpmath as mp
+    mp.mp.prec = 300
+    crm.crm_exp_fast_n.restype = C.c_long
+    crm.crm_log10_fast_n.restype = C.c_long
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    xs = np.concatenate([rng.uniform(-700, 700, n), rng.uniform(-60, 0, n),
+                         rng.integers(-64000, 64000, n // 4) * (math.log(2) / 64) * (1 + rng.normal(0, 1e-9, n // 4)),
+                         (rng.integers(-64000, 64000, n // 4) + 0.5) * (math.log(2) / 64)])
+    bad = C.c_long()
+    acc = crm.crm_exp_fast_n(P(xs), C.c_long(len(xs)), C.byref(bad))
+    assert bad.value == 0 and acc > 0.9999 * len(xs)
+    xl = np.concatenate([10.0 ** rng.uniform(-300, 300, n), rng.uniform(0.5, 2, n), 10.0 ** rng.uniform(-40, 0, n),
+                         np.repeat(1 + np.arange(0, 129) / 128.0, 50) * (1 + rng.normal(0, 1e-8, 129 * 50))])
+    acc = crm.crm_log10_fast_n(P(xl), C.c_long(len(xl)), C.byref(bad))
+    assert bad.value == 0 and acc > 0.999 * len(xl)
+    m = 1500
+    xe = np.concatenate([rng.uniform(-700, 700, m), rng.uniform(-1, 1, m)])
+    o = np.zeros(4 * len(xe))
+    crm.crm_exp_fast_raw_n(P(xe), P(o), C.c_long(len(xe)))
+    worst = 0.0
+    for x, row in zip(xe, o.reshape(-1, 4)):
+        if row[1] == 0:
+            continue
+        kd = round(x * 64 / math.log(2))
+        e = (kd - kd % 64) // 64
+        t = mp.exp(mp.mpf(float(x))) / mp.mpf(2) ** e
+        worst = max(worst, float(abs(mp.mpf(float(row[1])) + mp.mpf(float(row[2])) - t) / mp.mpf(float(row[3]))))
+    assert worst < 0.25, worst
+    xq = np.abs(np.concatenate([10.0 ** rng.uniform(-300, 300, m), rng.uniform(0.5, 2, m), 1 + rng.uniform(-1 / 256, 1 / 128, m), 10.0 ** rng.uniform(-40, 0, m)]))
+    o = np.zeros(4 * len(xq))
+    crm.crm_log10_fast_raw_n(P(xq), P(o), C.c_long(len(xq)))
+    worst = 0.0
+    for x, row in zip(xq, o.reshape(-1, 4)):
+        if row[3] == 0:
+            continue
+        worst = max(worst, float(abs(mp.mpf(float(row[1])) + mp.mpf(float(row[2])) - mp.log10(mp.mpf(float(x)))) / mp.mpf(float(row[3]))))
+    assert worst < 0.5, worst
+
+
 def _adversarial(rng, n):
     """Inputs around the table nodes and interval ends of both first stages, next to ordinary ones."""
     xs = np.concatenate([rng.uniform(-np.pi, np.pi, n), rng.uniform(-7, 7, n // 4),
@@ -175,4 +296,11 @@ def test_device_build_matches_host_build(crm, lsdmod):
     crm.crm_atan_n(P(v), P(o), len(v))
     do, _ = ctx.eval_math(2, v)
     assert np.array_equal(do, o)
+    # exp / log10 / pow (RectangleNFACalculator): subnormal results and arguments included
+    ex, xl, px, py = explog_samples(100000)
+    for fn, hostf, args in ((4, crm.crm_exp_n, (ex,)), (5, crm.crm_log10_n, (xl,)), (6, crm.crm_pow_n, (px, py))):
+        o = np.zeros(len(args[0]))
+        hostf(*[P(a) for a in args], P(o), C.c_long(len(o)))
+        do, _ = ctx.eval_math(fn, *args)
+        assert np.array_equal(do, o), fn
     ctx.close()
