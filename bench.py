@@ -326,12 +326,16 @@ def main():
         step(i, False)
     barrier()
     t0 = time.perf_counter()
-    res = None
+    res, res_slot = None, {}
     for i in range(a.steps):
         res = step(i, depth == 1, last=i >= a.steps - tail_help)
+        res_slot[i % depth] = res                          # the gathered result of every slot's last step (checked below, all of them)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    # the front end inside the timed region: HIP events of every slot's LAST step, event to event -- with several steps in flight that
+    # includes the wait for room beside the region stage's workgroups (one step at a time: kernel_ms below)
+    tr_front = [c_.timings() for c_ in ctxs[:min(depth, a.steps)]] if depth > 1 else []
     last = outs[(a.steps - 1) % depth]
     w_, h_ = lsd.scaled_size(size, size)
     timed_cyc = np.array([ctxs[(a.steps - 1) % depth].fetch(i, lsd.DBG_STATS, (w_, h_))["cycles_total"] for i in range(n)], np.float64) if rank == 0 else None
@@ -362,11 +366,12 @@ def main():
     overflow = int((last[1] > a.max_lines).sum().item())
 
     if rank == 0:
-        if use_dist:                                       # the gathered result of the last step: every line arrived, nothing overflowed
-            counts_all, slabs = res
+        if use_dist:                                       # the gathered results of the last step of EVERY slot in flight: every line arrived, nothing overflowed
             per, _ = lsd.gather_layout(n_total, world)
-            assert int(counts_all[:, :per].sum().item()) == int(total_lines) == int(counts_all[:, per].sum().item()), "lsd_gather_lines lost lines"
-            assert not bool(counts_all[:, per + 1].any().item()), "lsd_gather_lines: a slab overflowed"
+            for j, rj in sorted(res_slot.items()):
+                counts_all, slabs = rj
+                assert int(counts_all[:, :per].sum().item()) == int(total_lines) == int(counts_all[:, per].sum().item()), "lsd_gather_lines lost lines (slot %d)" % j
+                assert not bool(counts_all[:, per + 1].any().item()), "lsd_gather_lines: a slab overflowed or an image was given up (slot %d)" % j
         step_s = dt / a.steps
         mpix = n_total * size * size / 1e6
         grad_ms = kt["gradient"] / un_steps
@@ -416,6 +421,9 @@ def main():
                                            "(HIP events of a launch inside an overlapped region also time its wait for a CU)" if depth > 1 else "identical to the timed region"},
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
             "kernel_ms": {k: v / un_steps for k, v in kt.items()},
+            # the same kernels inside the timed region, event to event (mean over the slots' last steps): what the front end of a step
+            # takes while the region stages of the other steps in flight hold the CUs
+            "kernel_ms_in_timed_region": ({k: float(np.mean([t[k] for t in tr_front])) for k in ("gauss", "gradient", "sort", "region", "lines")} if tr_front else None),
             # informational: every kernel's HBM traffic (PMC, profiles/traffic_latest.json) over its live launch time
             "kernel_hbm_GBs": {k: traffic_all["k_" + k] / (kt[k] / un_steps * 1e-3) / 1e9
                                for k in ("gauss", "gradient", "sort", "region", "lines") if ("k_" + k) in traffic_all and kt[k] > 0},

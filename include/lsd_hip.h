@@ -117,6 +117,14 @@ int lsd_synchronize(lsd_ctx *ctx);
  * The only exchange is the result hand-off below.
  * lsd_shard_range: the contiguous shard [*lo, *hi) of n_items images that rank `rank` of `world` takes. */
 void lsd_shard_range(int n_items, int world, int rank, int *lo, int *hi);
+/* Cost-aware deal of the same shards: perm[n_items] orders the images such that rank r, taking perm[lo_r .. hi_r) (lsd_shard_range),
+ * carries about the same total cost as every other rank (longest-processing-time-first, deterministic; inside a shard ascending image
+ * index).  costs[i] >= 0: e.g. the region stage's cycles of image i in the previous step (lsd_last_region_cycles) -- maps of one site
+ * cost about the same from step to step.  The gathered lists then arrive in perm order: image perm[g] at position g. */
+int lsd_shard_balanced(const long long *costs, int n_items, int world, int *perm);
+/* Shader clocks the region stage spent on each of the first n images of the context's last batch (synchronises): the cost
+ * lsd_shard_balanced deals by.  An image the region stage gave up reports 0. */
+int lsd_last_region_cycles(lsd_ctx *ctx, int n, long long *cycles_out);
 
 /* A communicator as this library sees it: who am I, how many are we, and ONE operation -- an all-gather of equally sized device
  * buffers (d_recv holds world x bytes_per_rank, rank r's bytes at r * bytes_per_rank), enqueued on `stream`, 0 on success. */

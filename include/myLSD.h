@@ -18,6 +18,7 @@
 #define LSD_MYLSD_ADAPTER_H
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -176,6 +177,36 @@ inline MatF64 createMapCache(Mat MapGray, double res, double z_occ_max_dis_ = z_
                                  res, z_occ_max_dis_, out.template ptr<double>(0));
     if (st != LSD_OK) throw lsd_error(st, std::string(lsd_strerror(st)) + ": " + lsd_last_error(c));
     return out;
+}
+
+/* The replay driver's file formats (LSD/main_on_windows.cpp:27-46, main_on_linux.cpp's launch files point at the same data): mapParam.txt is
+ * "cols rows resolution originX originY"; mapValue.txt holds rows x cols decimal cell values, row-major, cols-then-rows, which the driver
+ * reads with fscanf("%d") straight into the uint8_t pixels -- i.e. every pixel keeps the LOW BYTE of its number (the three bytes the int
+ * store spills over are rewritten by the reads that follow).  These two helpers give a host that binds the adapter the same maps without
+ * the spill; false if the file is missing or short. */
+inline bool loadMapParam(const char* path, structMapParam* mp) {
+    FILE* fp = std::fopen(path, "r");
+    if (!fp) return false;
+    const int got = std::fscanf(fp, "%d %d %lf %lf %lf", &mp->oriMapCol, &mp->oriMapRow, &mp->mapResol, &mp->mapOriX, &mp->mapOriY);
+    std::fclose(fp);
+    return got == 5;
+}
+inline bool loadMapValue(const char* path, int oriMapCol, int oriMapRow, Mat* mapValue) {
+    FILE* fp = std::fopen(path, "r");
+    if (!fp) return false;
+    Mat m = make_u8(oriMapRow, oriMapCol);
+    bool ok = true;
+    for (int r = 0; r < oriMapRow && ok; r++) {
+        unsigned char* row = m.template ptr<unsigned char>(r);
+        for (int c = 0; c < oriMapCol; c++) {
+            int v;
+            if (std::fscanf(fp, "%d", &v) != 1) { ok = false; break; }
+            row[c] = (unsigned char)(v & 0xff);
+        }
+    }
+    std::fclose(fp);
+    if (ok) *mapValue = m;
+    return ok;
 }
 
 /* north_star's name for the same call, with the LSD/baseFunc.h:64-68 defaults */

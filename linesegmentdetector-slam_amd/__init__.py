@@ -140,6 +140,9 @@ def load_library(path=None):
     if hasattr(L, "lsd_gather_lines") or not os.environ.get("LSD_HIP_LIB"):
         L.lsd_shard_range.restype = None; L.lsd_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         L.lsd_gather_layout.restype = i; L.lsd_gather_layout.argtypes = [i, i, C.POINTER(i), C.POINTER(sz)]
+    if hasattr(L, "lsd_shard_balanced") or not os.environ.get("LSD_HIP_LIB"):
+        L.lsd_shard_balanced.restype = i; L.lsd_shard_balanced.argtypes = [vp, i, i, vp]
+        L.lsd_last_region_cycles.restype = i; L.lsd_last_region_cycles.argtypes = [vp, i, vp]
         L.lsd_comm_from_rccl.restype = i; L.lsd_comm_from_rccl.argtypes = [vp, C.POINTER(lsd_comm)]
         L.lsd_gather_lines.restype = i; L.lsd_gather_lines.argtypes = [vp, C.POINTER(lsd_comm), vp, vp, i, i, i, i, vp, vp, vp]
         L.lsd_gather_unpack.restype = i; L.lsd_gather_unpack.argtypes = [vp, vp, i, i, i, vp, vp, sz]
@@ -152,7 +155,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_set_host_max_lines",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_shard_balanced", "lsd_last_region_cycles", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
@@ -165,6 +168,16 @@ def shard_range(n_items, world, rank):
     lo, hi = C.c_int(), C.c_int()
     load_library().lsd_shard_range(n_items, world, rank, C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def shard_balanced(costs, world):
+    """lsd_shard_balanced -> perm int32 [n]: rank r takes images perm[lo_r:hi_r] (shard_range) and every rank carries about the same cost."""
+    c = np.ascontiguousarray(costs, np.int64)
+    perm = np.zeros(len(c), np.int32)
+    st = load_library().lsd_shard_balanced(c.ctypes.data, len(c), world, perm.ctypes.data)
+    if st != LSD_OK:
+        raise LsdError(st, load_library().lsd_strerror(st).decode())
+    return perm
 
 
 def gather_layout(n_total, world):
@@ -368,6 +381,12 @@ class Context:
         self._chk(self.L.lsd_debug_fetch(self.h, 0, DBG_STATS, a.ctypes.data, a.nbytes))
         return a
 
+    def last_region_cycles(self, n):
+        """lsd_last_region_cycles: shader clocks of the region stage per image of the last batch (the cost shard_balanced deals by)."""
+        a = np.zeros(n, np.int64)
+        self._chk(self.L.lsd_last_region_cycles(self.h, n, a.ctypes.data))
+        return a
+
     def timings(self):
         ms = (C.c_float * 6)()
         self._chk(self.L.lsd_last_timings(self.h, ms))
@@ -435,6 +454,7 @@ class Context:
                           "wait_noseed", "requeued_ahead", "cycles_eval_at_cursor", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "help_exports", "help_evals", "help_reclaims",
                           "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
                          [int(x) for x in v]))
+            d["set_answers"], d["sets_founded"] = int(v[41]), int(v[42])   # evaluations answered by a certified uniform set / sets founded (k_region.hip)
             d["nfa_bracket_misses"] = int(v[40])   # stopping tests of the NFA's tail left to the correctly rounded pow / log10 (an image the watchdog gave up keeps its record here instead)
             # how close RectangleImprover's comparisons came to a tie, relative: smallest |logNFA| / logNT compared with 0, smallest
             # non-zero |v - best| / max(|v|, |best|, logNT) of two compared NFA values (inf: none seen)

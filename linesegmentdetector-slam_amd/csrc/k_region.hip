@@ -86,6 +86,9 @@ constexpr int LMASK = LCAP - 1;
 constexpr int NT = LSD_REGION_NT;       // tile-cache slots per wave (8x8-pixel tiles of packed pixel words; a power of two; 16 measured as good as 32)
 static_assert((NT & (NT - 1)) == 0 && NT >= 8 && LCAP >= 256 && (LCAP & (LCAP - 1)) == 0, "tile slots and list ring: powers of two");
 constexpr int RING = 128;    // remembered bounding boxes of recently accepted lines
+constexpr int kSetMax = 255;           // certified sets per image and launch (labels 1 .. kSetMax)
+constexpr int kSetMinPixels = 64;      // ... of at least this many pixels
+constexpr uint32_t kSetPending = 0x80000000u;
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
@@ -111,7 +114,8 @@ struct RCtx {
     const double* mag;
     const double* deg;
     uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
-    uint32_t* epochmap;
+    uint32_t* epochmap;  // accept epoch of code-3 pixels; for growable pixels (code 0 / 2) the LABEL of the certified set they belong to (0: none)
+    uint32_t* sets;      // this image's certified sets (see "Certified uniform sets" below): [kSetMax + 1] sizes, 0 = dead / unused; null for a helper
     uint32_t* tep;       // per 8x8-pixel tile: epoch + 1 of the latest accepted line with a pixel in it (0: none)
     uint32_t* tmask;     // this wave's member masks of evicted tiles: 4 words per 8x8 tile (grow id, -, 64 member bits)
     uint32_t* spill;
@@ -134,7 +138,8 @@ struct RCtx {
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
        ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_COUNT };
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_SETHIT, ST_SETNEW, ST_COUNT };
+static_assert(ST_TOTAL == kStatTotalWord, "lsd_last_region_cycles reads this word");
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
@@ -144,10 +149,10 @@ constexpr int kStatSlots = ST_COUNT;
 __device__ constexpr int sslot(int i) { return i; }
 #else
 // the product build keeps the always-on counters only (LDS is the scarce resource of this kernel)
-constexpr int kStatSlots = 16;
+constexpr int kStatSlots = 18;
 __device__ constexpr int sslot(int i) {
     return i == ST_GROW ? 0 : i == ST_GROWN ? 1 : i == ST_NFA ? 2 : i == ST_RRR ? 3 : i == ST_RRRPASS ? 4 : i == ST_SENT ? 5 : i == ST_OOB ? 6 :
-           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : i == ST_XEXP ? 14 : i == ST_XHELP ? 15 : 11;
+           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : i == ST_XEXP ? 14 : i == ST_XHELP ? 15 : i == ST_SETHIT ? 16 : i == ST_SETNEW ? 17 : 11;
 }
 #endif
 #define STAT(i, v) do { g_stat[c.wave][sslot(i)] += (unsigned long long)(v); } while (0)
@@ -222,6 +227,8 @@ struct EvalOut {
     int x0, y0, x1, y1;      // box of the pixels of the grown lists (speculative evaluations only)
     int n1, n2, precise;     // sizes of the first grow and of Refiner's regrow kept in the slot (precise == 0: not kept)
     int m_off, mcnt, redo;   // where the pixels to mark sit in the slot; redo: the result does not fit a slot
+    int setid;               // != 0: the result was taken from certified set `setid` without growing anything (outcome 1)
+    int cert;                // 1: this evaluation went the way every seed of a uniform set goes (see certify_set): its first list may found a set
     double logNFA;
 };
 __shared__ EvalOut g_eo[NW];
@@ -1391,7 +1398,13 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
         // pixels out of it -- then curMap is in tmask (flush_tiles) and the grow-order copy is walked
         if (src || !has_copy || tm_member(c, x, y, cur_id)) {
             const uint32_t old = c.pw[q];
-            if (epoch1) { c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1); }
+            if (epoch1) {
+                if (c.sets) {                              // a banned member ends its certified set (the word holds the set's label until now)
+                    const uint32_t lb = c.epochmap[q];
+                    if (lb - 1u < (uint32_t)kSetMax) st_l2(&c.sets[lb], 0u);
+                }
+                c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1);
+            }
             else c.pw[q] = (old & ~3u) | kPwRejected;
             x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
         }
@@ -1423,6 +1436,120 @@ __device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) 
     return bx;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Certified uniform sets.
+//
+// A fifth of all pixels the bench batch grows, and nine tenths of its heaviest images', belong to a few sparse structures whose
+// pixels all have THE SAME level-line angle, bit for bit (long axis-parallel edges: the seams of the tiled maps, runs of wall),
+// grown again from every one of their hundreds of seeds: RegionGrower returns the same ~1 700 pixels, the rectangle around them is
+// far too sparse, Refiner re-estimates the tolerance from the pixels near the seed -- all with the seed's own angle, so the new
+// tolerance is exactly 0 --, regrows the seed alone and gives up (myLSD.cpp:833-861): nothing is marked, and the next seed of the
+// structure starts over (the reference does exactly that).  For such a set S the whole evaluation of ANY seed in S is known without
+// growing anything, provided
+//   (1) every pixel of S has the angle theta (fp64 equality) and is growable (not banned);
+//   (2) every growable pixel next to S that is not in S is further than tol + 1e-5 from theta (circular distance; for tol < pi/2 the
+//       reference's test :540-543 IS the circular distance; the 1e-5 covers the packed fp32 angle the check reads, 1.2e-6);
+//   (3) S is 8-connected (it is: it was grown as one region);
+//   (4) the rectangle of S is sparse by a margin: density < denThre (1 - 1e-3).
+// (1)-(3): whatever seed B in S the reference starts from, regDeg is theta at every step (the sum of equal unit vectors has their
+// direction; atan2's rounding is many orders below the 1e-5), every member passes its test the first time it comes up and every
+// other growable neighbour fails every time: RegionGrower returns S, |S| >= regThre.  (4): the density of the rectangle depends on
+// the list order only through the rounding of its sums (relative 1e-10 for 65 535 pixels), so it is below denThre for every seed.
+// Refiner then sees angle differences of exactly 0 (:839-853: degDif = theta - theta), tol = 2 sqrt(0) = 0, regrows the seed alone
+// (:857, `0 < 0` never holds) and fails at :861.  Outcome: no marks, first region |S| pixels, final region 1 pixel.
+//
+// Mechanics.  epochmap[] is free for growable pixels (it holds the accept epoch of banned ones): K2 clears it there and it carries
+// the LABEL of the pixel's set.  An evaluation that went exactly this way (EvalOut.cert) offers its first list: certify_set() checks
+// (1) and labels the members under the cursor lock -- the lock commits hold, so no ban can slip between check and label --, checks
+// (2) and publishes the set's size in sets[label].  A line that bans a member clears sets[label] (mark_region: the label is still in
+// the word it overwrites with the epoch).  Invariant: every member of a live set carries its label (a new set that takes over a
+// labelled pixel ends the older set).  eval_seed() looks at its seed's label first; a live set answers at once (EvalOut.setid).  The
+// result waits in the ring as R_SETL and is valid at its turn iff the set is still alive -- alive means no member was ever banned,
+// which is exactly "no member banned since the snapshot" for a result that has ALL of S as its list.  Wavefronts that help another
+// image neither use nor found sets (labels and table are read through this CU's caches).
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ int certify_set(int cw_, uint32_t pp_, int slot_, int n_, int* lock_, int* nsets_) {
+    const int wave = uni(cw_);
+    const int lane = (int)(threadIdx.x & 63);
+    const RCtx c = g_ctx[wave];
+    const int w = uni(c.w), h = uni(c.h), n = uni(n_);
+    const uint32_t pp = (uint32_t)uni((int)pp_);
+    const uint32_t* const list = c.wslist + (size_t)uni(slot_) * uni(c.gcap);     // the first grow's list, kept for the cursor's validation
+    uint32_t* const sets = c.sets;
+    {   // the structure has its set already (another wavefront's evaluation of a neighbouring seed got here first): nothing to found
+        const uint32_t lb0 = (uint32_t)uni((int)c.epochmap[pp]);
+        if (lb0 - 1u < (uint32_t)kSetMax && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) return 0;
+    }
+    int got = 0;
+    if (lane == 0) got = atomicCAS(lock_, 0, 1) == 0 ? 1 : 0;                     // (busy: the next seed of the structure will offer again)
+    if (!uni(got)) return 0;
+    {   // (again under the lock: labels and table only change under it)
+        const uint32_t lb0 = (uint32_t)uni((int)c.epochmap[pp]);
+        if (lb0 - 1u < (uint32_t)kSetMax && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) {
+            if (lane == 0) __hip_atomic_store(lock_, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return 0;
+        }
+    }
+    int id = 0;
+    if (lane == 0) { id = *nsets_ + 1; if (id <= kSetMax) *nsets_ = id; }
+    id = uni(id);
+    bool bad = id > kSetMax;
+    if (!bad) {
+        // (1) + labels, under the lock
+        const double theta = c.deg[pp];
+        for (int base = 0; base < n; base += 64) {
+            const int k2 = base + lane;
+            if (k2 < n) {
+                const uint32_t pk = list[k2];
+                const size_t q = (size_t)(pk >> 16) * w + (pk & 0xffffu);
+                const uint32_t code = c.pw[q] & 3u;
+                if (code != kPwFree && code != kPwRejected) bad = true;              // banned meanwhile (its word holds the line's epoch: hands off)
+                else {
+                    if (c.deg[q] != theta) bad = true;
+                    const uint32_t lb = c.epochmap[q];
+                    if (lb - 1u < (uint32_t)kSetMax && lb != (uint32_t)id) st_l2(&sets[lb], 0u);   // an older set loses a pixel: it ends
+                    c.epochmap[q] = (uint32_t)id;
+                }
+            }
+        }
+        bad = ballot64(bad) != 0ull;
+        if (lane == 0) st_l2(&sets[id], bad ? 0u : ((uint32_t)n | kSetPending));
+        wg_fence();
+    }
+    if (lane == 0) __hip_atomic_store(lock_, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (bad) return 0;
+    // (2) the growable neighbours outside S, without the lock: a pixel that fails now fails for good (bans only grow, angles never change)
+    const float thf = __uint_as_float(c.pw[pp] & ~3u);
+    const float lim = (float)g_tol0[0] + 1e-5f;
+    const int e = lane >> 3, k8 = lane & 7, kk = k8 + (k8 >= 4);
+    const int ox = kk % 3 - 1, oy = kk / 3 - 1;
+    for (int base = 0; base < n; base += 8) {
+        const int k2 = base + e;
+        if (k2 < n) {
+            const uint32_t pk = list[k2];
+            const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
+            if (((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h)) {
+                const size_t q = (size_t)ny * w + nx;
+                const uint32_t wq = c.pw[q], lb = c.epochmap[q];
+                const uint32_t code = wq & 3u;
+                if ((code == kPwFree || code == kPwRejected) && lb != (uint32_t)id) {
+                    float d = fabsf(__uint_as_float(wq & ~3u) - thf);
+                    if (d > (float)kPi) d = 2.0f * (float)kPi - d;
+                    if (d < lim) bad = true;
+                }
+            }
+        }
+    }
+    bad = ballot64(bad) != 0ull;
+    int alive = 0;
+    if (lane == 0) {
+        if (bad) st_l2(&sets[id], 0u);
+        else alive = atomicCAS(&sets[id], (uint32_t)n | kSetPending, (uint32_t)n) == ((uint32_t)n | kSetPending) ? 1 : 0;   // (0 meanwhile: a member was banned)
+    }
+    return uni(alive) ? id : 0;
+}
+
 // One seed's evaluation, RegionGrower ... RectangleImprover (:225-240), with all 64 lanes of the wave; pp = the seed's pixel.
 // A speculative evaluation (spec != 0) also leaves in result slot `slot` what the commit at the cursor will need: the first
 // grow's list and Refiner's regrow (their pixels decide whether the result is still valid at its turn), and the pixels to mark.
@@ -1447,7 +1574,26 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
     int outcome = 0, num = 0, num0 = 0, rec_pk = 0;
     double logNFA = 0;
     const bool skip = uni((int)(g_ctx[wave].pw[pp] & 3u)) != 0;   // monotone: once used, always used (:222)
+    eo.setid = 0; eo.cert = 0;
+    if (!skip && g_ctx[wave].sets) {
+        // a seed of a live certified set: the evaluation is known (see "Certified uniform sets")
+        const uint32_t lb = (uint32_t)uni((int)g_ctx[wave].epochmap[pp]);
+        if (lb - 1u < (uint32_t)kSetMax) {
+            const uint32_t ns = (uint32_t)uni((int)ld_l2(&g_ctx[wave].sets[lb]));
+            if (ns >= (uint32_t)kSetMinPixels && ns < kSetPending && (double)ns >= p_regThre) {
+                RCtx c = g_ctx[wave]; c.lane = lane;
+                STAT(ST_GROW, 2); STAT(ST_GROWN, ns + 1u);             // (RegionGrower's two calls of the reference, as the work counters count them)
+                STAT(ST_SETHIT, 1);
+                eo.skip = 0; eo.outcome = 1; eo.num = 1; eo.num0 = (int)ns; eo.rec_pk = 0; eo.logNFA = 0;
+                eo.redo = 0; eo.precise = 0; eo.n1 = 0; eo.n2 = 0; eo.m_off = 0; eo.mcnt = 1;
+                eo.x0 = 0; eo.y0 = 0; eo.x1 = -1; eo.y1 = -1;
+                eo.setid = (int)lb;
+                return;
+            }
+        }
+    }
     int fx0 = 0x7fffffff, fy0 = 0x7fffffff, fx1 = -1, fy1 = -1;   // box of a first grow that refine() replaced
+    bool sparse_by_margin = false, tol_zero = false;
     // list slot of a speculative evaluation: [first grow (n1)][Refiner's regrow (n2)][pixels to mark, if not one of those]
     int n1 = -1;                                       // -1: the lists are not kept (validation by bounding box only)
     bool regrown = false;
@@ -1477,12 +1623,14 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
             const double den = uni(rec_density(num, g_ws[wave].rec));
             if (pass == 0) {
                 if (den >= p_denThre) break;                                      // :829 dense enough
+                sparse_by_margin = den < p_denThre * (1.0 - 1e-3);
                 if (spec) {                                                       // the regrow replaces this list
                     Box fb; fb.x0 = fx0; fb.y0 = fy0; fb.x1 = fx1; fb.y1 = fy1;
                     fb = list_bbox(wave, num, fb, false);
                     fx0 = uni(fb.x0); fy0 = uni(fb.y0); fx1 = uni(fb.x1); fy1 = uni(fb.y1);
                 }
                 tol = uni(refine_tol(wave, sx, sy, num, seedDeg));                     // :833-855
+                tol_zero = tol == 0.0;
             } else if (den < p_denThre) {                                         // :869-877
                 const int r = uni(radius_reduce(wave, sx, sy, num, regdeg, p_denThre));   // (lst reordered: gcopy holds the grow-order list)
                 if (r < 0) { num = -r - 1; outcome = 1; done = true; }
@@ -1497,6 +1645,9 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
     }
     eo.skip = skip ? 1 : 0; eo.outcome = outcome; eo.num = num; eo.num0 = num0; eo.rec_pk = rec_pk; eo.logNFA = logNFA;
     eo.redo = 0; eo.precise = 0; eo.n1 = 0; eo.n2 = 0; eo.m_off = 0; eo.mcnt = num;
+    // the way every seed of a uniform set goes: a sparse first region, a re-estimated tolerance of exactly 0, the seed alone, given up
+    eo.cert = (spec && !skip && outcome == 1 && regrown && num == 1 && sparse_by_margin && tol_zero && n1 == num0 && num0 >= kSetMinPixels &&
+               num0 <= 65535 && p_degThre < 1.5 && g_ctx[wave].sets != nullptr) ? 1 : 0;
     if (!spec || skip) return;
 
     const int gnum = uni(g_ws[wave].gnum);             // size of the last grow (grow order)
@@ -1580,8 +1731,10 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 //   R_REMOTE given to the wavefronts of other workgroups that help with this image (aux = request number); R_XLIGHTL / R_XSTASH:
 //            their answers, R_LIGHTL / R_STASH with the lists and the record in the HELPER's result slot (aux = request number,
 //            the slot and the box in the request table)
+//   R_SETL   the seed belongs to a live certified set (aux = its label): the evaluation is known without growing anything (no marks);
+//            valid at the cursor iff the set is still alive
 enum { R_EMPTY = 0, R_SKIP = 1, R_LIGHT = 2, R_REDO = 3, R_BUSY = 4, R_STASH = 5, R_BIG = 6, R_EVAL = 7, R_LIGHTL = 8,
-       R_REMOTE = 9, R_XLIGHTL = 10, R_XSTASH = 11 };
+       R_REMOTE = 9, R_XLIGHTL = 10, R_XSTASH = 11, R_SETL = 12 };
 constexpr int kHelpIdle = 50;             // looks without a request after which a helper wavefront leaves an image
 constexpr int RW = 256 * NW;              // records in flight: how far the hand-out may run ahead of the cursor
 constexpr int CH = 32;                    // seeds a wave reserves at a time (its chunk)
@@ -1615,7 +1768,7 @@ __device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
 __device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATTR void k_region(Geom g, Buffers b, uint32_t id_base) {
-    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort;
+    __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort, s_nsets;
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
     __shared__ SlotTab stab;
@@ -1642,6 +1795,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     RCtx c;
     c.w = w; c.h = h; c.lane = lane; c.wave = wave;
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
+    c.sets = (pool || !b.sets) ? nullptr : b.sets + img * (size_t)(kSetMax + 1);
     c.tep = b.tepoch + img * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
     c.sc = b.sc + img * npx;
     c.tmask = b.stamps + (img * NW + wave) * (size_t)b.tm_stride;
@@ -1663,6 +1817,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     if (lane < NT) g_ttag[c.wave][lane] = -1;
     for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
     if (threadIdx.x < kXReq) s_xk[threadIdx.x] = -1;
+    if (c.sets) for (int j = threadIdx.x; j <= kSetMax; j += 64 * NW) st_l2(&c.sets[j], 0u);   // no certified set yet (K2 has cleared the labels)
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;
@@ -1690,7 +1845,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
             cnt += __builtin_popcountll(m);
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(cnt, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
+        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(cnt, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nsets = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
         wg_fence();
         if (xr) agent_release();                           // helpers on other XCDs read seedpos[] as soon as a request names a seed
     }
@@ -1797,6 +1952,10 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                 const double* P = b.pend + (img * (size_t)(NW * NS) + rg.aux[rr]) * 24;
                 x0 = (int)P[18]; y0 = (int)P[19]; x1 = (int)P[20]; y1 = (int)P[21];
             }
+            if (stl == R_SETL && ld_l2(&c.sets[rg.aux[rr]]) == 0u) {           // its set ended (with this line, or earlier): a full evaluation then
+                st_st(&rg.state[rr], R_BIG); atomicAdd(&s_nbig, 1);
+                DSTAT(ST_DEPTHUP, 1);
+            }
             unsigned long long hm = ballot64(!(mb.x1 < x0 || mb.x0 > x1 || mb.y1 < y0 || mb.y0 > y1) && x1 >= x0);
             while (hm) {
                 const int l = __builtin_ctzll(hm);
@@ -1870,6 +2029,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                 const int stl = idx < nseeds ? st_ld(&rg.state[rr]) : R_EMPTY;
                 const uint32_t sp = idx < nseeds ? seedpos[idx] : 0u;           // (used only when a box has to be placed)
                 bool ok = stl == R_SKIP;
+                if (stl == R_SETL) ok = ld_l2(&c.sets[rg.aux[rr]]) != 0u;          // (alive: no member of the set was ever banned)
                 if (stl == R_LIGHT || stl == R_LIGHTL) {
                     const int d = (now - (int)rg.snap[rr]) & 0xffff;
                     ok = d == 0;
@@ -1939,6 +2099,21 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                 if (st == R_XLIGHTL && lane == 0) s_xk[ax] = -1;
                 bool used_now = false;
                 if (trace) used_now = (c.pw[seedpos[f]] & 3u) != 0u;          // the reference skips it then (:222): no record
+                if (trace && !used_now) {
+                    const int no = rnum[r * 2 + 1];
+                    write_trace(f, rnum[r * 2], no >> 2, no & 3, 0.0);
+                } else if (!trace) write_trace(f, 0, 0, 0, 0.0);
+                if (lane == 0) { rg.state[r] = (uint8_t)R_EMPTY; lds_st(&s_commit, f + 1); }
+                continue;
+            }
+            if (st == R_SETL) {
+                if (ld_l2(&c.sets[rg.aux[r]]) == 0u) {                             // the set ended before the seed's turn: evaluate in full, here
+                    STAT(ST_REDO, 1);
+                    if (lane == 0) { st_st(&rg.state[r], R_REDO); lds_st(&s_depth, max(depth_min, lds_ld(&s_depth) - kDepthDown)); }
+                    break;
+                }
+                bool used_now = false;
+                if (trace) used_now = (c.pw[seedpos[f]] & 3u) != 0u;               // the reference skips it then (:222): no record
                 if (trace && !used_now) {
                     const int no = rnum[r * 2 + 1];
                     write_trace(f, rnum[r * 2], no >> 2, no & 3, 0.0);
@@ -2170,7 +2345,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             const int s0 = f0 < nseeds ? st_ld(&rg.state[f0 & (RW - 1)]) : R_EMPTY;
             LT(ST_TSELECT);
             adv = false;
-            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH || s0 == R_XLIGHTL || s0 == R_XSTASH) advance();
+            if (s0 == R_SKIP || s0 == R_LIGHT || s0 == R_LIGHTL || s0 == R_STASH || s0 == R_XLIGHTL || s0 == R_XSTASH || s0 == R_SETL) advance();
             else if (s0 == R_REMOTE) xwant = 2;
             LT(ST_TCOMMIT);
         }
@@ -2471,7 +2646,17 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         LT(ST_TEVAL);
         if (!spec) {
             // ---- evaluated at the cursor (k == s_commit, record R_BUSY: nobody else can commit): commit right away ----
-            if (!skip && outcome >= 2) commit_marks(k, num0, num, outcome, logNFA, pv, nullptr, 0);
+            if (!skip && outcome >= 2) {
+                // (under the cursor lock although nobody else can commit here: certify_set() relies on no ban appearing while it holds it)
+                while (true) {
+                    int got = 0;
+                    if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0 ? 1 : 0;
+                    if (__builtin_amdgcn_readfirstlane(got)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                commit_marks(k, num0, num, outcome, logNFA, pv, nullptr, 0);
+                if (lane == 0) lds_st(&s_lock, 0);
+            }
             else if (!skip) write_trace(k, num0, outcome == 0 ? num0 : num, outcome, logNFA);
             wg_fence();
             if (lane == 0) { rg.state[k & (RW - 1)] = (uint8_t)R_EMPTY; lds_st(&s_commit, k + 1); }
@@ -2482,6 +2667,18 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         if (skip) {
             if (lane == slot) slot_k_l = -1;               // nothing kept in the slot
             if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_SKIP);
+            adv = true;
+            continue;
+        }
+        if (eo.setid) {                                    // answered by a certified set: nothing is kept in the slot
+            if (lane == slot) slot_k_l = -1;
+            if (lane == 0) {
+                const int r = k & (RW - 1);
+                rg.snap[r] = (uint16_t)epoch_snap;
+                rg.aux[r] = (uint32_t)eo.setid;
+                if (trace) { rnum[r * 2] = num0; rnum[r * 2 + 1] = (num << 2) | outcome; }
+                st_st(&rg.state[r], R_SETL);
+            }
             adv = true;
             continue;
         }
@@ -2499,6 +2696,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             wg_fence();                                    // the lists are in the slot before the record says so
             if (lane == 0) st_st(&rg.state[k & (RW - 1)], R_LIGHTL);
             adv = true;
+            // an evaluation that went the way of a uniform set offers its first list (still in the slot) as a certified set
+            if (eo.cert && certify_set(c.wave, pp, slot, num0, &s_lock, &s_nsets)) STAT(ST_SETNEW, 1);
             continue;
         }
         // marks to make: the result is stashed (record in pend[], the pixels to mark in the list slot); whoever moves the
@@ -2612,11 +2811,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             hx = (int)im; hrec = rc; hidle = 0; hscan = 0;
             cur_seedpos = b.seedpos + (size_t)im * npx;
             c.mag = b.mag + (size_t)im * npx; c.deg = b.deg + (size_t)im * npx; c.pw = b.pw + (size_t)im * npx;
-            c.epochmap = b.epochmap + (size_t)im * npx; c.sc = b.sc + (size_t)im * npx;
+            c.epochmap = b.epochmap + (size_t)im * npx; c.sc = b.sc + (size_t)im * npx; c.sets = nullptr;
             c.tep = b.tepoch + (size_t)im * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
             if (lane == 0) {
                 RCtx& gc = g_ctx[wave];
-                gc.mag = c.mag; gc.deg = c.deg; gc.pw = c.pw; gc.epochmap = c.epochmap; gc.sc = c.sc; gc.tep = c.tep;
+                gc.mag = c.mag; gc.deg = c.deg; gc.pw = c.pw; gc.epochmap = c.epochmap; gc.sc = c.sc; gc.tep = c.tep; gc.sets = nullptr;
                 g_ws[wave].cache_epoch = -1;
             }
             wg_fence();

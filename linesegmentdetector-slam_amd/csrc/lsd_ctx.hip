@@ -45,6 +45,7 @@ struct lsd_ctx {
     double *gauss = nullptr, *mag = nullptr, *deg = nullptr, *recs = nullptr, *recs_scaled = nullptr;
     double2* sc = nullptr;
     uint32_t* order = nullptr;
+    uint32_t *sets = nullptr;            // n x 256: certified sets of the region stage (k_region.hip)
     uint32_t *pw = nullptr, *epochmap = nullptr, *ord = nullptr, *spill = nullptr, *gcopy = nullptr, *stamps = nullptr, *seedidx = nullptr, *seedpos = nullptr, *tepoch = nullptr;
     uint32_t run_id = 0;   // curMap stamps are unique per run: (run_id << 20) + grow number (a wave that uses up its 2^20 clears its stamps)
     uint32_t* slist = nullptr;
@@ -301,6 +302,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
         HIPCHK(c, re_alloc(&c->pend, gs * 24));
         HIPCHK(c, re_alloc(&c->order, nn));
+        HIPCHK(c, re_alloc(&c->sets, nn * 256));
         HIPCHK(c, re_alloc(&c->xq, nn * (size_t)(kXStride + 1) + kXHdr));
         HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
         HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
@@ -330,7 +332,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int ma
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
                          (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
-                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order, (void**)&c->xq,
+                         (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order, (void**)&c->xq, (void**)&c->sets,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
         for (void** pp : ptrs) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
@@ -444,7 +446,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->sets, c->wmeta, c->rnum, c->ordv,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf, c->ga_cnt, c->ga_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -530,7 +532,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     Buffers b{};
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
-    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.maxbits = c->maxbits; b.nb = c->nb;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb;
     b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
     b.tm_stride = 4 * ((g.w + 7) >> 3) * ((g.h + 7) >> 3);
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
@@ -734,6 +736,15 @@ int lsd_run(lsd_ctx* c, uint8_t* map, int cols, int rows, size_t stride, const l
         for (int y = 0; y < rows; y++) memcpy(line_im + (size_t)y * line_im_stride, &tim[(size_t)y * cols], cols);
     *n_lines = offs[1];
     return st;
+}
+
+int lsd_last_region_cycles(lsd_ctx* c, int n, long long* cycles_out) {
+    if (!c || !cycles_out || n <= 0 || n > c->last_n) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy2D(cycles_out, sizeof(long long), c->stats + kStatTotalWord, sizeof(long long) * kStatWords, sizeof(long long), (size_t)n,
+                          hipMemcpyDeviceToHost));
+    return LSD_OK;
 }
 
 int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {

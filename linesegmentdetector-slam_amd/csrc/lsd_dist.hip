@@ -19,7 +19,9 @@ constexpr ncclDataType_t ncclInt8 = 0;
 
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "lsd_internal.h"
 
@@ -71,6 +73,30 @@ void lsd_shard_range(int n_items, int world, int rank, int* lo, int* hi) {
     const long long n = n_items, w = world, r = rank;
     if (lo) *lo = (int)((r * n + w - 1) / w);
     if (hi) *hi = (int)(((r + 1) * n + w - 1) / w);
+}
+
+// Cost-aware deal: perm[] orders the images such that the contiguous shards lsd_shard_range gives the ranks carry about the same cost.
+// Longest-processing-time-first: the images by descending cost (ties: ascending index), each to the rank with the least cost so far
+// among those whose shard still has room; inside a shard the images keep ascending index.  Deterministic.
+int lsd_shard_balanced(const long long* costs, int n_items, int world, int* perm) {
+    if (!costs || !perm || n_items <= 0 || world <= 0) return LSD_ERR_INVALID;
+    std::vector<int> idx(n_items), room(world), lo(world);
+    std::vector<long long> load(world, 0);
+    std::vector<std::vector<int>> bin(world);
+    for (int r = 0; r < world; r++) { int a, b; lsd_shard_range(n_items, world, r, &a, &b); lo[r] = a; room[r] = b - a; }
+    for (int i = 0; i < n_items; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return costs[a] > costs[b]; });
+    for (int i : idx) {
+        int best = -1;
+        for (int r = 0; r < world; r++)
+            if (room[r] > 0 && (best < 0 || load[r] < load[best])) best = r;
+        bin[best].push_back(i); load[best] += costs[i] > 0 ? costs[i] : 0; room[best]--;
+    }
+    for (int r = 0; r < world; r++) {
+        std::sort(bin[r].begin(), bin[r].end());
+        for (size_t k = 0; k < bin[r].size(); k++) perm[lo[r] + (int)k] = bin[r][k];
+    }
+    return LSD_OK;
 }
 
 int lsd_gather_layout(int n_total, int world, int* per_rank, size_t* counts_words) {

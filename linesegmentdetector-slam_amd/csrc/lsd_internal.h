@@ -11,6 +11,7 @@ constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per 
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries every context starts with; it grows to w*h + 2 (the largest
 constexpr int kLgTableMax = 1 << 23;            //    pixel count a rectangle can have, + 1), up to this many
 constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
+constexpr int kStatTotalWord = 8;               // ... of which this one holds the shader clocks the stage spent on the image (k_region.hip: ST_TOTAL)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
 // Help across workgroups in the region stage (k_region.hip): a control block of 32-bit words per launch, cleared before it.
 //   per image (kXStride words): [0] accept epoch [1] commit cursor [2] image finished [3] helper wavefronts attached
@@ -55,7 +56,8 @@ struct Buffers {
     double* deg;           // n x npx
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
     uint32_t* pw;          // n x npx : packed pixel word (see above)
-    uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3 (never initialised, read only behind code 3)
+    uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3; for growable pixels (K2 clears it there) the label of their certified set (k_region.hip)
+    uint32_t* sets;        // n x 256 : sizes of the certified sets of the launch by label, 0 = none / ended (cleared by the region stage itself)
     uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length

@@ -122,6 +122,41 @@ def test_cpp_adapter_compiles(built, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
 
 
+def test_cpp_adapter_loads_the_replay_drivers_map_files(built, maps, tmp_path):
+    """mylsd::loadMapParam / loadMapValue (include/myLSD.h): the text formats LSD/main_on_windows.cpp:27-46 reads -- "cols rows resolution
+    originX originY" and rows x cols decimal cell values -- give the adapter's caller the same bytes as the fixtures (which
+    tests/golden/make_fixtures.py read from the reference's data/*.txt the same way); values above 255 keep their low byte, as the
+    driver's fscanf("%d") into a uint8_t does."""
+    img = maps["map1"][:40, :56].copy()
+    txt = tmp_path / "mapValue.txt"
+    vals = img.astype(np.int64)
+    vals[3, 5] += 256                                             # (a cell value with more than 8 bits)
+    txt.write_text("\n".join(" ".join(str(int(v)) for v in row) for row in vals) + "\n")
+    (tmp_path / "mapParam.txt").write_text("56 40 0.025 -4.43187 -5.49357\n")
+    src = tmp_path / "t.cpp"
+    src.write_text(
+        '#include "myLSD.h"\n'
+        '#include <cstdio>\n'
+        'int main(int argc, char** argv) {\n'
+        '  structMapParam mp; mylsd::Mat m;\n'
+        '  if (!mylsd::loadMapParam(argv[1], &mp) || !mylsd::loadMapValue(argv[2], mp.oriMapCol, mp.oriMapRow, &m)) return 2;\n'
+        '  if (mylsd::loadMapValue(argv[1], mp.oriMapCol, mp.oriMapRow, &m)) return 3;      /* a short file is refused */\n'
+        '  std::printf("%d %d %.5f %.5f %.5f\\n", mp.oriMapCol, mp.oriMapRow, mp.mapResol, mp.mapOriX, mp.mapOriY);\n'
+        '  for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.cols; c++) std::printf("%d\\n", (int)m.ptr<unsigned char>(r)[c]);\n'
+        '  return 0;\n'
+        '}\n')
+    exe = tmp_path / "t"
+    pkg = os.path.join(ROOT, "linesegmentdetector-slam_amd")
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", pkg, "-llsdhip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    p = subprocess.run([str(exe), str(tmp_path / "mapParam.txt"), str(txt)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.split("\n")
+    assert lines[0] == "56 40 0.02500 -4.43187 -5.49357"
+    got = np.array([int(x) for x in lines[1:] if x], np.uint8).reshape(40, 56)
+    assert np.array_equal(got, img)
+
+
 # A header with the include guard and the colliding names of the reference's LSD/baseFunc.h (:20-88): what a caller that
 # has the reference tree sees under that file name.  (Test double written here: the real one pulls in Eigen, absent in
 # this image; only the guard and the names matter for the collision.)

@@ -244,12 +244,16 @@ def test_batch_is_deterministic_run_to_run(maps, lsdmod, ctx):
     import bench
     batch = bench.make_batch(maps, 48, 1024)
     ref = None
-    for _ in range(5):
-        lines, offs, ims = ctx.run_batch(batch.copy())
-        cur = (lines.tobytes(), offs.tobytes(), ims.tobytes())
-        if ref is None:
-            ref = cur
-        assert cur == ref
+    try:
+        for rep in range(12):                                      # both builds of the region stage in turn (certified sets are founded by
+            ctx.set_region_waves(4 if rep % 2 else 0)              # whichever evaluation gets there first: the results must not show it)
+            lines, offs, ims = ctx.run_batch(batch.copy())
+            cur = (lines.tobytes(), offs.tobytes(), ims.tobytes())
+            if ref is None:
+                ref = cur
+            assert cur == ref, rep
+    finally:
+        ctx.set_region_waves(0)
 
 
 def test_non_packed_stride(maps, lsdmod, ctx, oracle):
@@ -781,6 +785,42 @@ def test_default_variant_for_long_batches(maps, lsdmod, ctx, oracle):
         j = i % 44
         assert offs[i + 1] - offs[i] == offs[j + 1] - offs[j]
         assert lines[offs[i]:offs[i + 1]].tobytes() == lines[offs[j]:offs[j + 1]].tobytes()
+
+
+def test_certified_uniform_sets_answer_like_full_evaluations(maps, lsdmod, ctx, oracle):
+    """The heaviest bench images are one sparse structure of pixels with the SAME level-line angle, grown again from each of its
+    hundreds of seeds and given up by Refiner every time (k_region.hip, "Certified uniform sets").  The region stage founds a set from
+    the first such evaluation and answers the structure's other seeds without growing anything.  Every seed's record -- first region,
+    final region, outcome, logNFA -- must be the oracle's, with the trace on (every record through the cursor one by one) and off, and
+    most of the structure's seeds must have been answered by the set."""
+    import bench
+    for i in (187, 16):
+        img = bench.make_image(maps, i, 2048)
+        ref = oracle.lsd(img.copy(), debug=True)
+        d = ref["dbg"]
+        rs = d["seeds"]
+        big1 = int(((rs["outcome"] == 1) & (rs["num"] >= 256)).sum())
+        assert big1 > 100
+        ctx.set_trace(True)
+        try:
+            ctx.run(img.copy(), want_lineim=False)
+            seeds = ctx.fetch(0, lsdmod.DBG_SEEDS, (d["w"], d["h"]))
+            st = ctx.fetch(0, lsdmod.DBG_STATS, (d["w"], d["h"]))
+        finally:
+            ctx.set_trace(False)
+        assert len(seeds) == len(rs)
+        for f in ("order_idx", "x", "y", "num", "outcome", "final_num"):
+            assert np.array_equal(seeds[f], rs[f]), (i, f)
+        assert st["sets_founded"] >= 1 and st["set_answers"] >= big1 // 2, (i, st["sets_founded"], st["set_answers"], big1)
+        for waves in (4, 8):
+            ctx.set_region_waves(waves)
+            try:
+                lines, im = ctx.run(img.copy())
+            finally:
+                ctx.set_region_waves(0)
+            used = (ctx.fetch(0, lsdmod.DBG_STATE, (d["w"], d["h"])) & 3).astype(np.uint8)
+            assert np.array_equal(used, d["used"]) and np.array_equal(im, ref["lineIm"])
+            assert_lines_close(lines, ref["lines"])
 
 
 def test_nfa_values_equal_the_correctly_rounded_restatement(maps, lsdmod, ctx, oracle):
