@@ -456,8 +456,8 @@ class Context:
                          [int(x) for x in v]))
             d["set_answers"], d["sets_founded"] = int(v[41]), int(v[42])   # evaluations answered by a certified uniform set / sets founded (k_region.hip)
             d["nfa_bracket_misses"] = int(v[40])   # stopping tests of the NFA's tail left to the correctly rounded pow / log10 (an image the watchdog gave up keeps its record here instead)
-            # how close RectangleImprover's comparisons came to a tie, relative: smallest |logNFA| / logNT compared with 0, smallest
-            # non-zero |v - best| / max(|v|, |best|, logNT) of two compared NFA values (inf: none seen)
+            # how close RectangleImprover's comparisons came to a tie, as margins (distance of the operands over what an ulp of exp / log10 /
+            # pow can move them; k_region.hip: improve()): smallest for a logNFA compared with 0, smallest for two compared NFA values (inf: none seen)
             for k in ("nfa_min_abs", "nfa_min_gap"):
                 enc = d.pop(k + "_enc")
                 d[k] = float("inf") if enc == 0 else float(np.array([0x7ff0000000000000 - enc], np.uint64).view(np.float64)[0])

@@ -37,7 +37,7 @@ constexpr int CAP = 256;
 
 __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gauss, double* __restrict__ mag,
                                                  double* __restrict__ deg, double2* __restrict__ sc,
-                                                 uint32_t* __restrict__ pw, uint32_t* __restrict__ labels,
+                                                 uint32_t* __restrict__ pw,
                                                  unsigned long long* __restrict__ maxbits, int w, int h, int gp,
                                                  double gradThre, unsigned gx, unsigned gy, unsigned strips) {
     __shared__ uint32_t l_px[CAP];           // (strip-local pixel index << 1) | growable
@@ -168,7 +168,6 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
                 const size_t p = base + (size_t)y * w + x;
                 deg[p] = rowD[r];
                 pw[p] = pack_pw(rowD[r], rowU[r]);
-                if (rowU[r] == 0) labels[p] = 0u;          // growable: no certified set yet (the region stage keeps its set labels where banned pixels keep their epoch)
             }
         }
     }
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const unsigned gx = (g.w + GX - 1) / GX, gy = (g.h + GR - 1) / GR, strips = gx * gy * (unsigned)n;
-    hipLaunchKernelGGL(k_gradient, dim3(((strips + 7u) >> 3) * 8u), dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.epochmap, b.maxbits,
+    hipLaunchKernelGGL(k_gradient, dim3(((strips + 7u) >> 3) * 8u), dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits,
                        g.w, g.h, g.gp, g.gradThre, gx, gy, strips);
 }
 

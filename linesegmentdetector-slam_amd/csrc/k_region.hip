@@ -89,6 +89,10 @@ constexpr int RING = 128;    // remembered bounding boxes of recently accepted l
 constexpr int kSetMax = 255;           // certified sets per image and launch (labels 1 .. kSetMax)
 constexpr int kSetMinPixels = 64;      // ... of at least this many pixels
 constexpr uint32_t kSetPending = 0x80000000u;
+// The label of a growable pixel (in its epochmap word): bit 31 | the launch's tag << 8 | set number.  Accept epochs (small integers) and
+// the labels of earlier launches in the same buffers never look like one of THIS launch (the tag is the run number, as for the stamps).
+__device__ __forceinline__ uint32_t label_make(uint32_t tag, uint32_t id) { return 0x80000000u | (tag << 8) | id; }
+__device__ __forceinline__ uint32_t label_set(uint32_t tag, uint32_t word) { return (word >> 8) == (0x800000u | tag) ? (word & 0xffu) : 0u; }
 
 struct Rec {  // structRec, myLSD.h:80-93 (+ pk = number of halvings of p, indexes the host log tables)
     double x1, y1, x2, y2, wid, cX, cY, deg, dx, dy, p, prec;
@@ -115,6 +119,7 @@ struct RCtx {
     const double* deg;
     uint32_t* pw;        // packed pixel words: fp32 angle | usedMap code (shared by the workgroup)
     uint32_t* epochmap;  // accept epoch of code-3 pixels; for growable pixels (code 0 / 2) the LABEL of the certified set they belong to (0: none)
+    uint32_t ltag;       // the launch's label tag (see label_make)
     uint32_t* sets;      // this image's certified sets (see "Certified uniform sets" below): [kSetMax + 1] sizes, 0 = dead / unused; null for a helper
     uint32_t* tep;       // per 8x8-pixel tile: epoch + 1 of the latest accepted line with a pixel in it (0: none)
     uint32_t* tmask;     // this wave's member masks of evicted tiles: 4 words per 8x8 tile (grow id, -, 64 member bits)
@@ -1314,13 +1319,19 @@ __device__ __noinline__ double improve(int cw_) {
         if (!eval) continue;
         bool host_only;
         const double v = rect_nfa(c, r, host_only);
-        // how close the two comparisons below come to a tie, RELATIVE to the magnitudes that set their rounding noise (logNT and the
-        // compared values): what a last-place difference between two libms could turn (tools/campaign.py enforces a floor).  A value
-        // made of the host's numbers alone (-logNT - n log10 p: an exact 0 exists, w h = 6^4, p = 1/6, n = 10) is the reference's own.
+        // How close the two comparisons below come to a tie, as a MARGIN: the distance of the operands over the most the reference's
+        // libm (glibc: exp and pow within 1 ulp, log10 within 1 ulp of the correctly rounded values computed here) can move them apart.
+        // v = fl(-L - logNT) with L = log10(tail): |dL| <= 2^-51 |L| + 2^-53 (the tail's first term differs by an ulp), and the
+        // subtraction rounds to an ulp of max(|v|, logNT): noise(v) = 2^-51 |v + logNT| + 2^-52 (1 + max(|v|, logNT)).  A decision can come
+        // out differently on the two libms only where the margin is below 1 (tools/campaign.py enforces a floor of 2).  A value made of
+        // the host's numbers alone (-logNT - n log10 p: an exact 0 exists, w h = 6^4, p = 1/6, n = 10) is the reference's own.
         if (fabs(v) <= 1.7976931348623157e308) {
-            if (!host_only) STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v) / c.logNT));       // (v is compared with 0: :1075, :242)
-            if (step > 0 && v != bestNFA)
-                STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA) / fmax(fmax(fabs(v), fabs(bestNFA)), c.logNT)));
+            const double nv = 0x1p-51 * fabs(v + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(v), c.logNT));
+            if (!host_only) STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v) / nv));       // (v is compared with 0: :1075, :242)
+            if (step > 0 && v != bestNFA) {
+                const double nb = 0x1p-51 * fabs(bestNFA + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(bestNFA), c.logNT));
+                STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA) / (nv + nb)));
+            }
         }
         if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
         else if (v > bestNFA) { bestNFA = v; best = r; }
@@ -1400,8 +1411,8 @@ __device__ __noinline__ Box mark_region(int cw_, uint32_t epoch1, const uint32_t
             const uint32_t old = c.pw[q];
             if (epoch1) {
                 if (c.sets) {                              // a banned member ends its certified set (the word holds the set's label until now)
-                    const uint32_t lb = c.epochmap[q];
-                    if (lb - 1u < (uint32_t)kSetMax) st_l2(&c.sets[lb], 0u);
+                    const uint32_t lb = label_set(c.ltag, c.epochmap[q]);
+                    if (lb) st_l2(&c.sets[lb], 0u);
                 }
                 c.epochmap[q] = epoch1; c.pw[q] = (old & ~3u) | kPwLine; atomicMax(&c.tep[(y >> 3) * c.tilesX + (x >> 3)], epoch1);
             }
@@ -1459,8 +1470,8 @@ __device__ __noinline__ Box list_bbox(int cw_, int num, Box in, bool from_copy) 
 // Refiner then sees angle differences of exactly 0 (:839-853: degDif = theta - theta), tol = 2 sqrt(0) = 0, regrows the seed alone
 // (:857, `0 < 0` never holds) and fails at :861.  Outcome: no marks, first region |S| pixels, final region 1 pixel.
 //
-// Mechanics.  epochmap[] is free for growable pixels (it holds the accept epoch of banned ones): K2 clears it there and it carries
-// the LABEL of the pixel's set.  An evaluation that went exactly this way (EvalOut.cert) offers its first list: certify_set() checks
+// Mechanics.  epochmap[] is free for growable pixels (it holds the accept epoch of banned ones): there it carries the LABEL of the
+// pixel's set, tagged with the launch's run number (label_make: what earlier launches left in the buffer is no label of this one).  An evaluation that went exactly this way (EvalOut.cert) offers its first list: certify_set() checks
 // (1) and labels the members under the cursor lock -- the lock commits hold, so no ban can slip between check and label --, checks
 // (2) and publishes the set's size in sets[label].  A line that bans a member clears sets[label] (mark_region: the label is still in
 // the word it overwrites with the epoch).  Invariant: every member of a live set carries its label (a new set that takes over a
@@ -1478,15 +1489,15 @@ __device__ __noinline__ int certify_set(int cw_, uint32_t pp_, int slot_, int n_
     const uint32_t* const list = c.wslist + (size_t)uni(slot_) * uni(c.gcap);     // the first grow's list, kept for the cursor's validation
     uint32_t* const sets = c.sets;
     {   // the structure has its set already (another wavefront's evaluation of a neighbouring seed got here first): nothing to found
-        const uint32_t lb0 = (uint32_t)uni((int)c.epochmap[pp]);
-        if (lb0 - 1u < (uint32_t)kSetMax && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) return 0;
+        const uint32_t lb0 = label_set(c.ltag, (uint32_t)uni((int)c.epochmap[pp]));
+        if (lb0 && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) return 0;
     }
     int got = 0;
     if (lane == 0) got = atomicCAS(lock_, 0, 1) == 0 ? 1 : 0;                     // (busy: the next seed of the structure will offer again)
     if (!uni(got)) return 0;
     {   // (again under the lock: labels and table only change under it)
-        const uint32_t lb0 = (uint32_t)uni((int)c.epochmap[pp]);
-        if (lb0 - 1u < (uint32_t)kSetMax && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) {
+        const uint32_t lb0 = label_set(c.ltag, (uint32_t)uni((int)c.epochmap[pp]));
+        if (lb0 && (uint32_t)uni((int)ld_l2(&sets[lb0])) != 0u) {
             if (lane == 0) __hip_atomic_store(lock_, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             return 0;
         }
@@ -1507,9 +1518,9 @@ __device__ __noinline__ int certify_set(int cw_, uint32_t pp_, int slot_, int n_
                 if (code != kPwFree && code != kPwRejected) bad = true;              // banned meanwhile (its word holds the line's epoch: hands off)
                 else {
                     if (c.deg[q] != theta) bad = true;
-                    const uint32_t lb = c.epochmap[q];
-                    if (lb - 1u < (uint32_t)kSetMax && lb != (uint32_t)id) st_l2(&sets[lb], 0u);   // an older set loses a pixel: it ends
-                    c.epochmap[q] = (uint32_t)id;
+                    const uint32_t lb = label_set(c.ltag, c.epochmap[q]);
+                    if (lb && lb != (uint32_t)id) st_l2(&sets[lb], 0u);   // an older set loses a pixel: it ends
+                    c.epochmap[q] = label_make(c.ltag, (uint32_t)id);
                 }
             }
         }
@@ -1531,7 +1542,7 @@ __device__ __noinline__ int certify_set(int cw_, uint32_t pp_, int slot_, int n_
             const int nx = (int)(pk & 0xffffu) + ox, ny = (int)(pk >> 16) + oy;
             if (((unsigned)nx < (unsigned)w) & ((unsigned)ny < (unsigned)h)) {
                 const size_t q = (size_t)ny * w + nx;
-                const uint32_t wq = c.pw[q], lb = c.epochmap[q];
+                const uint32_t wq = c.pw[q], lb = label_set(c.ltag, c.epochmap[q]);
                 const uint32_t code = wq & 3u;
                 if ((code == kPwFree || code == kPwRejected) && lb != (uint32_t)id) {
                     float d = fabsf(__uint_as_float(wq & ~3u) - thf);
@@ -1577,8 +1588,8 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
     eo.setid = 0; eo.cert = 0;
     if (!skip && g_ctx[wave].sets) {
         // a seed of a live certified set: the evaluation is known (see "Certified uniform sets")
-        const uint32_t lb = (uint32_t)uni((int)g_ctx[wave].epochmap[pp]);
-        if (lb - 1u < (uint32_t)kSetMax) {
+        const uint32_t lb = label_set((uint32_t)uni((int)g_ctx[wave].ltag), (uint32_t)uni((int)g_ctx[wave].epochmap[pp]));
+        if (lb) {
             const uint32_t ns = (uint32_t)uni((int)ld_l2(&g_ctx[wave].sets[lb]));
             if (ns >= (uint32_t)kSetMinPixels && ns < kSetPending && (double)ns >= p_regThre) {
                 RCtx c = g_ctx[wave]; c.lane = lane;
@@ -1796,6 +1807,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     c.w = w; c.h = h; c.lane = lane; c.wave = wave;
     c.mag = b.mag + img * npx; c.deg = b.deg + img * npx; c.pw = b.pw + img * npx; c.epochmap = b.epochmap + img * npx;
     c.sets = (pool || !b.sets) ? nullptr : b.sets + img * (size_t)(kSetMax + 1);
+    c.ltag = (id_base >> 20) & 0x3ffu;
     c.tep = b.tepoch + img * (size_t)(((w + 7) >> 3) * ((h + 7) >> 3));
     c.sc = b.sc + img * npx;
     c.tmask = b.stamps + (img * NW + wave) * (size_t)b.tm_stride;
@@ -1817,7 +1829,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     if (lane < NT) g_ttag[c.wave][lane] = -1;
     for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
     if (threadIdx.x < kXReq) s_xk[threadIdx.x] = -1;
-    if (c.sets) for (int j = threadIdx.x; j <= kSetMax; j += 64 * NW) st_l2(&c.sets[j], 0u);   // no certified set yet (K2 has cleared the labels)
+    if (c.sets) for (int j = threadIdx.x; j <= kSetMax; j += 64 * NW) st_l2(&c.sets[j], 0u);   // no certified set yet (labels of earlier launches carry another tag)
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;

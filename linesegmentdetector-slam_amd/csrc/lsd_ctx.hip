@@ -297,6 +297,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
         HIPCHK(c, re_alloc(&c->stamps, ws * tm_words(pp))); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * tm_words(pp) * sizeof(uint32_t)));
+        HIPCHK(c, hipMemset(c->epochmap, 0, tot * sizeof(uint32_t)));
         c->run_id = 0;
         const size_t gs = ws * (size_t)region_slots();                          // result slots: NS per wave slot
         HIPCHK(c, re_alloc(&c->slist, gs * (size_t)c->gcap));
@@ -571,6 +572,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
         if (++c->run_id >= 1023u) {
             HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * tm_words(c->cap_npx) * sizeof(uint32_t), s));
+            HIPCHK(c, hipMemsetAsync(c->epochmap, 0, c->cap_n * c->cap_npx * sizeof(uint32_t), s));   // (the set labels carry the run number too)
             c->run_id = 1;
         }
         HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));

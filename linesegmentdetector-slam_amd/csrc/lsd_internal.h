@@ -56,7 +56,7 @@ struct Buffers {
     double* deg;           // n x npx
     double2* sc;           // n x npx : (sin, cos)(deg), written where usedMap == 0 after the gradient pass
     uint32_t* pw;          // n x npx : packed pixel word (see above)
-    uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3; for growable pixels (K2 clears it there) the label of their certified set (k_region.hip)
+    uint32_t* epochmap;    // n x npx : accept epoch of pixels with code 3; for growable pixels the label of their certified set, tagged with the run number (k_region.hip; cleared with the stamps when the run numbers wrap)
     uint32_t* sets;        // n x 256 : sizes of the certified sets of the launch by label, 0 = none / ended (cleared by the region stage itself)
     uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)

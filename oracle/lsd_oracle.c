@@ -432,10 +432,14 @@ static double rectangle_nfa(orc_state *st, const orc_rec *rec)
 static double note_nfa(orc_state *st, double v, double best, int first)
 {
     if (st->dbg && fabs(v) <= DBL_MAX) {
-        const double a = fabs(v) / st->logNT;
+        /* margins: distance over the most two libms (each within an ulp of the correctly rounded exp / log10 / pow) can move the
+         * operands apart -- noise(v) = 2^-51 |v + logNT| + 2^-52 (1 + max(|v|, logNT)), see k_region.hip: improve() */
+        const double nv = 0x1p-51 * fabs(v + st->logNT) + 0x1p-52 * (1.0 + fmax(fabs(v), st->logNT));
+        const double a = fabs(v) / nv;
         if (!st->nfa_host_only && a < st->dbg->nfa_min_abs) st->dbg->nfa_min_abs = a;   /* (-logNT - n log10 p: host numbers on the HIP path too) */
         if (!first && v != best) {
-            const double g = fabs(v - best) / fmax(fmax(fabs(v), fabs(best)), st->logNT);
+            const double nb = 0x1p-51 * fabs(best + st->logNT) + 0x1p-52 * (1.0 + fmax(fabs(best), st->logNT));
+            const double g = fabs(v - best) / (nv + nb);
             if (g < st->dbg->nfa_min_gap) st->dbg->nfa_min_gap = g;
         }
     }

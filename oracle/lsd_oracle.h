@@ -52,9 +52,9 @@ typedef struct {
     double *recs;         /* [n_lines*12] accepted structRec before rescale: x1 y1 x2 y2 wid cX cY deg dx dy p prec */
     /* counters */
     long grow_calls, grown_px, nfa_calls, rrr_calls, rrr_passes, rrr_sentinel_drops, rrr_oob_reads;
-    /* how close RectangleImprover's comparisons came to a tie, relative to the magnitudes that set their rounding noise: the
-     * smallest |logNFA| / logNT it compared with 0 (:1075, :242) and the smallest non-zero |v - best| / max(|v|, |best|, logNT) of
-     * two NFA values it compared (:1086 ...); HUGE_VAL: none */
+    /* how close RectangleImprover's comparisons came to a tie, as margins (>= 1: two libms within an ulp of the correctly rounded
+     * functions cannot decide differently): the smallest |logNFA| / noise of a value compared with 0 (:1075, :242) and the smallest
+     * |v - best| / (noise(v) + noise(best)) of two different NFA values compared (:1086 ...); HUGE_VAL: none */
     double nfa_min_abs, nfa_min_gap;
 } orc_debug;
 

@@ -867,12 +867,11 @@ def test_device_libm_is_inside_the_nfa_bracket(lsdmod, ctx):
 def test_nfa_decisions_are_far_from_ties(maps, lsdmod, ctx):
     """RectangleImprover's decisions (logNFA > 0, candidate > best so far) are those of correctly rounded arithmetic (above); glibc's
     exp / log10 / pow are not correctly rounded (test_crmath.py: log10 off by one ulp in one call out of seven), so a decision of the
-    reference could differ where an NFA value sits within a few ulp of 0 or of the value it is compared with.  The region stage
-    records the closest calls RELATIVE to the magnitudes that set the rounding noise (|v| / logNT; |v - best| / max(|v|, |best|,
-    logNT)).  What the data holds are STRUCTURAL near-ties: the binomial tail B(1/p + 1, 1/p, p) equals p^(1/p - 1) = B(1/p - 1, 1/p - 1, p)
-    exactly, and the two evaluations (the sum through the Lanczos / Windschitl log-gamma, the closed form) differ by the log-gamma
-    formulas' own error, ~3e-13 absolute = >= 100 ulp for p = 1/6, 1/8, 1/9 -- the same on every libm.  On every fixture and on the
-    whole 512-image bench batch nothing comes closer than 2e-14 relative (90 ulp), twenty times what two libms can differ by."""
+    reference could differ where two compared values sit within what those last places can move them.  The region stage records every
+    comparison's MARGIN -- the distance of its operands over that noise (k_region.hip: improve()); below 1 a flip is possible.  What
+    comes closest are STRUCTURAL near-ties: the binomial tail B(1/p + 1, 1/p, p) equals p^(1/p - 1) = B(1/p - 1, 1/p - 1, p) exactly, and
+    the two evaluations (the sum through the Lanczos / Windschitl log-gamma, the closed form) differ by the log-gamma formulas' own
+    error, ~3e-13 absolute -- the same on every libm.  On every fixture and on the whole 512-image bench batch every margin is >= 10."""
     import torch
     import bench
     lo_abs, lo_gap, calls = float("inf"), float("inf"), 0
@@ -893,8 +892,8 @@ def test_nfa_decisions_are_far_from_ties(maps, lsdmod, ctx):
     del d, d_lines
     torch.cuda.empty_cache()
     assert calls > 1_000_000
-    assert lo_abs >= 2e-14, lo_abs
-    assert lo_gap >= 2e-14, lo_gap
+    assert lo_abs >= 10, lo_abs
+    assert lo_gap >= 10, lo_gap
 
 
 def test_rccl_gather_runs_on_the_gpu(maps, lsdmod, ctx):
