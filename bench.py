@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--waves", type=int, default=-1, choices=(-1, 0, 4, 8), help="wavefronts per image of the region stage in the timed region: 0 = the library's choice "
                     "(8 for this batch size: lowest latency of one batch), 4 = two images per CU (highest throughput per CU); -1 = 4 with several steps in flight, else 0")
     ap.add_argument("--help-waves", type=int, default=0, help="helper wavefronts per image (lsd_set_region_help) while several steps are in flight (experiments; 0 = off)")
+    ap.add_argument("--cost-history", action="store_true", help="experiments: lsd_set_cost_history(1) on every context of the timed region")
     ap.add_argument("--tail-help", type=int, default=0, help="experiments: the last N steps of the timed region are enqueued with the help across workgroups ON (no further "
                     "step will come to fill the CUs their last images leave idle); measured with 20 steps at depth 8: 0 / 4 / 7 / 8 -> 44.9 / 45.3 / 46.8 / 68.4 ms per step")
     a = ap.parse_args()
@@ -283,6 +284,8 @@ def main():
     for c_ in ctxs:
         if depth > 1:
             c_.set_region_help(a.help_waves)
+        if a.cost_history:
+            c_.set_cost_history(True)
         c_.set_region_waves(waves)                          # (before reserve: the per-wave workspace is sized for the variant)
         c_.reserve(n, size, size)
     w, h = lsd.scaled_size(size, size)
@@ -341,7 +344,7 @@ def main():
     timed_cyc = np.array([ctxs[(a.steps - 1) % depth].fetch(i, lsd.DBG_STATS, (w_, h_))["cycles_total"] for i in range(n)], np.float64) if rank == 0 else None
     # One step at a time, after the timed region when that ran with several in flight: the per-kernel figures (inside an
     # overlapped region a launch's HIP events also time its wait for a CU) and the step time of a single batch, help on.
-    un_steps, un_dt = a.steps, dt
+    un_steps, un_dt, hist_dt = a.steps, dt, None
     if depth > 1:
         ctx.set_region_help(-1)
         ctx.set_region_waves(0)
@@ -355,6 +358,18 @@ def main():
         torch.cuda.synchronize()
         barrier()
         un_dt = time.perf_counter() - t1
+        # ... and the same with the scheduling hint a caller that re-extracts the SAME maps step after step can give (lsd_set_cost_history:
+        # the images start in the order of their cost in the previous call instead of by their count of gradient pixels)
+        ctx.set_cost_history(True)
+        step(0, False); step(0, False)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(un_steps):
+            step(0, False)
+        torch.cuda.synchronize()
+        barrier()
+        hist_dt = time.perf_counter() - t2
+        ctx.set_cost_history(False)
         depth = depth_saved
     tmax = torch.tensor([dt, un_dt], dtype=torch.float64, device=dev)
     nl = last[1].sum().to(torch.float64).reshape(1)
@@ -419,6 +434,9 @@ def main():
             "one_step_at_a_time": {"steps": un_steps, "ms_per_step": un_step_s * 1e3, "value": mpix / un_step_s, "unit": "Mpix/s",
                                    "note": "a batch alone on the GPU, help across workgroups on; kernel_ms, roofline and dominant_kernel are from these steps "
                                            "(HIP events of a launch inside an overlapped region also time its wait for a CU)" if depth > 1 else "identical to the timed region"},
+            "one_step_at_a_time_with_cost_history": ({"ms_per_step": hist_dt / un_steps * 1e3, "value": mpix / (hist_dt / un_steps), "unit": "Mpix/s",
+                                                     "note": "lsd_set_cost_history(1): the same batch again, its images started in the order of their cost in the previous "
+                                                             "step (a caller re-extracting one site's maps); rank 0's clock, not part of `value`"} if hist_dt else None),
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
             "kernel_ms": {k: v / un_steps for k, v in kt.items()},
             # the same kernels inside the timed region, event to event (mean over the slots' last steps): what the front end of a step

@@ -256,6 +256,11 @@ int lsd_set_region_waves(lsd_ctx *ctx, int waves);
  * should switch it off: the next batch's workgroups fill the idle CUs, and helpers would hold them (bench.py does exactly that).
  * Results do not depend on the setting. */
 int lsd_set_region_help(lsd_ctx *ctx, int waves);
+/* Scheduling hint: "the batches this context gets hold the same maps from call to call" (a site's maps, re-extracted as they are
+ * updated).  The region stage then starts the images in descending order of the time each one took in the context's previous call with
+ * the same number of images, instead of by their count of gradient pixels (which predicts the cost poorly): a batch run alone ends with
+ * its heaviest image, and that image should start first.  Off by default; results never depend on it. */
+int lsd_set_cost_history(lsd_ctx *ctx, int on);
 /* Test hook: the region stage marks the pixels of the region it is growing with a fresh 32-bit id per grow; a wavefront that
  * uses up its 2^20 ids within one run clears its stamp array and starts over.  That takes more than a million grows by one
  * wavefront on one image; this lowers the budget (2 .. 0xFFFF0 grows) so that tests reach the path.  Results do not change. */

@@ -117,6 +117,8 @@ def load_library(path=None):
     L.lsd_set_region_waves.restype = i; L.lsd_set_region_waves.argtypes = [vp, i]
     L.lsd_set_region_help.restype = i; L.lsd_set_region_help.argtypes = [vp, i]
     L.lsd_debug_set_stamp_budget.restype = i; L.lsd_debug_set_stamp_budget.argtypes = [vp, C.c_uint]
+    if hasattr(L, "lsd_set_cost_history") or not os.environ.get("LSD_HIP_LIB"):
+        L.lsd_set_cost_history.restype = i; L.lsd_set_cost_history.argtypes = [vp, i]
     if hasattr(L, "lsd_debug_set_tuning") or not os.environ.get("LSD_HIP_LIB"):
         L.lsd_debug_set_tuning.restype = i; L.lsd_debug_set_tuning.argtypes = [vp, C.c_char_p, i]
     L.lsd_set_host_max_lines.restype = i; L.lsd_set_host_max_lines.argtypes = [vp, i]
@@ -155,7 +157,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_shard_balanced", "lsd_last_region_cycles", "lsd_set_host_max_lines",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_set_cost_history", "lsd_shard_balanced", "lsd_last_region_cycles", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
@@ -402,6 +404,10 @@ class Context:
     def set_host_max_lines(self, max_lines):
         """Line capacity per image of run / run_batch (default 8192); more lines -> LsdError(LSD_ERR_CAPACITY)."""
         self._chk(self.L.lsd_set_host_max_lines(self.h, max_lines))
+
+    def set_cost_history(self, on):
+        """lsd_set_cost_history: start the images of a batch in the order of their cost in this context's previous call (same maps from call to call)."""
+        self._chk(self.L.lsd_set_cost_history(self.h, 1 if on else 0))
 
     def debug_set_tuning(self, name, value):
         """Test / developer hook (lsd_debug_set_tuning): a schedule setting of the region stage by name; no result depends on any."""

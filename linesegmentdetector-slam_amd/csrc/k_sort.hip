@@ -140,16 +140,30 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     }
 }
 
-// Heaviest images first: the region stage costs roughly what the number of sortable pixels says, and its workgroups are
-// dispatched in index order, so the batch is handed to it in descending order of nb (longest-processing-time-first
-// keeps the tail of the launch short).  One workgroup; counting sort of the images over 256 quantised keys.
-__global__ __launch_bounds__(256) void k_order(const int32_t* __restrict__ nb, uint32_t* __restrict__ order, int n, int npx) {
+// Heaviest images first: the region stage's workgroups are dispatched in index order, so the batch is handed to it in descending
+// order of expected cost (longest-processing-time-first keeps the tail of the launch short).  The expectation: the number of sortable
+// pixels (correlation with the measured cost ~0.4) -- or, when the caller says the batch holds the same maps as the context's last one
+// (lsd_set_cost_history: a site's maps change little from step to step), the shader clocks the stage spent on each image last time
+// (`hist`: the previous launch's counter records, still in place when this kernel runs).  One workgroup; counting sort over 256 keys.
+__global__ __launch_bounds__(256) void k_order(const int32_t* __restrict__ nb, const long long* __restrict__ hist, uint32_t* __restrict__ order, int n, int npx) {
     __shared__ uint32_t cnt[256];
     __shared__ uint32_t start[256];
+    __shared__ unsigned long long hmax;
     const int tid = threadIdx.x;
     cnt[tid] = 0;
+    if (tid == 0) hmax = 1ull;
     __syncthreads();
-    auto key = [&](int i) { return 255 - (int)min(255ll, (long long)nb[i] * 2048 / (npx + 1)); };   // (nb is ~7 % of npx on occupancy maps)
+    if (hist) {
+        unsigned long long m = 0;
+        for (int i = tid; i < n; i += 256) m = max(m, (unsigned long long)max(hist[(size_t)i * kStatWords + kStatTotalWord], 0ll));
+        atomicMax(&hmax, m);
+        __syncthreads();
+    }
+    const unsigned long long hm = hmax;
+    auto key = [&](int i) {
+        if (hist) return 255 - (int)(((unsigned long long)max(hist[(size_t)i * kStatWords + kStatTotalWord], 0ll) * 255ull) / hm);
+        return 255 - (int)min(255ll, (long long)nb[i] * 2048 / (npx + 1));   // (nb is ~7 % of npx on occupancy maps)
+    };
     for (int i = tid; i < n; i += 256) atomicAdd(&cnt[key(i)], 1u);
     __syncthreads();
     if (tid == 0) {
@@ -163,8 +177,8 @@ __global__ __launch_bounds__(256) void k_order(const int32_t* __restrict__ nb, u
         if (key(i) == tid) order[pos++] = (uint32_t)i;
 }
 
-void launch_order(const Buffers& b, int n, int npx, hipStream_t s) {
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(256), 0, s, b.nb, b.order, n, npx);
+void launch_order(const Buffers& b, int n, int npx, const long long* hist, hipStream_t s) {
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(256), 0, s, b.nb, hist, b.order, n, npx);
 }
 
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s) {

@@ -73,6 +73,8 @@ struct lsd_ctx {
     // tables
     double *d_taps = nullptr, *d_lgamma = nullptr, *d_ptab = nullptr;
     int lg_count = 0;                   // entries of d_lgamma
+    bool cost_history = false;          // lsd_set_cost_history: the region stage takes the images in the order of their cost in the last launch
+    int hist_n = 0;                     // images of the launch whose counter records are in `stats` (0: none)
     lsd_params tab_params{};
     bool tab_valid = false;
     int tapR = 0;
@@ -482,6 +484,12 @@ int lsd_set_region_help(lsd_ctx* c, int waves) {
     return LSD_OK;
 }
 
+int lsd_set_cost_history(lsd_ctx* c, int on) {
+    if (!c) return LSD_ERR_INVALID;
+    c->cost_history = on != 0;
+    return LSD_OK;
+}
+
 int lsd_debug_set_tuning(lsd_ctx* c, const char* name, int value) {
     if (!c || !name) return LSD_ERR_INVALID;
     for (const Tuning& t : kTunings)
@@ -566,7 +574,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_GRAD) launch_gradient(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) { launch_sort(g, b, n, s); launch_order(b, n, g.npx, s); }
+    if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) { launch_sort(g, b, n, s); launch_order(b, n, g.npx, (c->cost_history && c->hist_n == n && !c->trace) ? c->stats : nullptr, s); }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
@@ -591,6 +599,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     c->done_valid = true;
     HIPCHK(c, hipGetLastError());
     c->ev_valid = true;
+    c->hist_n = (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) ? n : 0;     // (the counter records of this launch: the next one's cost history)
     c->geom = g; c->last_n = n; c->last_max_lines = max_lines; c->last_counts = d_counts; c->last_stream = s;
     return LSD_OK;
 }

@@ -117,7 +117,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
-void launch_order(const Buffers& b, int n, int npx, hipStream_t s);
+void launch_order(const Buffers& b, int n, int npx, const long long* hist, hipStream_t s);   // hist: the last launch's counter records (cost history) or null
 // the region stage with 4 resp. 8 wavefronts per image (k_region.hip is compiled twice)
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
 void launch_region_w8(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
