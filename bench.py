@@ -546,21 +546,31 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
     # -- strong scaling projected from ONE GPU (BASELINE configs[4]: the same batch split over 2 / 4 / 8 GPUs, contiguous shards):
     #    every shard is run alone on this GPU; a step of the sharded job cannot be shorter than its slowest shard (+ the gather, 22 MB)
     if a.scaling == "weak" and n_total >= 8:
-        def run_shard(lo, hi):
+        def run_shard(lo, hi, src=None):
+            src = d_maps if src is None else src
             best = 1e9
             for _ in range(2):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                ctx.enqueue_device(d_maps[lo:hi].data_ptr(), hi - lo, size, size, d_lines[lo:hi].data_ptr(), a.max_lines, d_counts[lo:hi].data_ptr(),
+                ctx.enqueue_device(src[lo:hi].data_ptr(), hi - lo, size, size, d_lines[lo:hi].data_ptr(), a.max_lines, d_counts[lo:hi].data_ptr(),
                                    d_line_ims=None if d_ims is None else d_ims[lo:hi].data_ptr(), stream=stream)
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t1) * 1e3)
             return best
         t_all = run_shard(0, n_total)
+        # the cost-aware deal (lsd_shard_balanced) by the cycles every image took in that run: the batch re-ordered so that the same
+        # contiguous shards carry about the same cost (the gathered lists then arrive in that order, image perm[g] at position g)
+        costs = ctx.last_region_cycles(n_total)
         proj = {"1": {"max_shard_ms": t_all, "speedup": 1.0}}
+        perms = {}
         for world in (2, 4, 8):
             ts = [run_shard(*ldist.shard_range(n_total, world, r)) for r in range(world)]
             proj[str(world)] = {"max_shard_ms": max(ts), "min_shard_ms": min(ts), "speedup": t_all / max(ts)}
+            perms[world] = lsd.shard_balanced(costs, world)
+            d_bal = d_maps[torch.from_numpy(perms[world].astype(np.int64)).to(dev)]
+            tb_ = [run_shard(*ldist.shard_range(n_total, world, r), src=d_bal) for r in range(world)]
+            proj[str(world)].update({"balanced_max_shard_ms": max(tb_), "balanced_min_shard_ms": min(tb_), "balanced_speedup": t_all / max(tb_)})
+            del d_bal
         # the same split in THROUGHPUT mode: what an N-GPU job sees when every rank keeps `depth` steps in flight on its shard
         # (contexts ctxs[], 4-wave region stage, help off -- the configuration of this line's `value`), ms per sharded step
         depth1 = len(ctxs)
@@ -569,16 +579,17 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
             # as many steps in flight (the same number of images, up to 32 steps).  The 1-GPU figure comes from the timed region's own
             # contexts; they are then closed (a context's workspace is ~40 MB per image) and every shard size gets contexts and outputs
             # of its own, sized for the shard.
-            def run_pipelined(lo, hi, slots):
+            def run_pipelined(lo, hi, slots, src=None):
                 # ms per step at the steady RATE of the pipeline: every step's completion is time-stamped (an event on its stream), and the
                 # rate is taken between the dw-th completion and the moment the first slot runs out of queued steps.  (Timing a fixed
                 # number of steps per slot instead measures the most crowded hardware queue: 32 streams are dealt onto 16 queues, not
                 # always two each -- rocprofv3's Queue_Id showed 3 + 1 on two of them after an earlier launch in the process -- and a
                 # rank that refills whichever slot is free does not wait for that queue.  DESIGN_NOTES.md, "The strong split".)
                 m, dw = hi - lo, len(slots)
+                src = d_maps if src is None else src
                 def go(i):
                     cx, st_, l_, c2, im_ = slots[i % dw]
-                    cx.enqueue_device(d_maps[lo:hi].data_ptr(), m, size, size, l_.data_ptr(), a.max_lines, c2.data_ptr(),
+                    cx.enqueue_device(src[lo:hi].data_ptr(), m, size, size, l_.data_ptr(), a.max_lines, c2.data_ptr(),
                                       d_line_ims=None if im_ is None else im_.data_ptr(), stream=st_.cuda_stream)
                 for i in range(dw):
                     go(i)
@@ -616,6 +627,11 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
                     proj[str(world)].update({"pipelined_max_shard_ms_per_step": max(ts), "pipelined_min_shard_ms_per_step": min(ts),
                                              "pipelined_speedup": t1_all / max(ts), "pipelined_steps_in_flight": dw,
                                              "pipelined_shard_ms_per_step": [round(t, 2) for t in ts]})
+                    d_bal = d_maps[torch.from_numpy(perms[world].astype(np.int64)).to(dev)]          # the same with the cost-aware deal
+                    tb_ = [run_pipelined(*ldist.shard_range(n_total, world, r), slots, src=d_bal) for r in range(world)]
+                    proj[str(world)].update({"pipelined_balanced_max_shard_ms_per_step": max(tb_), "pipelined_balanced_min_shard_ms_per_step": min(tb_),
+                                             "pipelined_balanced_speedup": t1_all / max(tb_)})
+                    del d_bal
                     for sl in slots:
                         sl[0].close()
                     del slots
@@ -625,7 +641,7 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
             ctx.set_region_help(-1); ctx.set_region_waves(0)
         out["strong_scaling_projection"] = {"gpus": proj, "note_throughput_mode": "pipelined_*: every shard run on this one GPU in the timed region's configuration with pipelined_steps_in_flight steps in flight "
                                             "(%d x the number of GPUs, at most 32: the same number of images in flight as the 1-GPU job); "
-                                            "a sharded job in throughput mode advances at its slowest shard's rate" % depth1, "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
+                                            "a sharded job in throughput mode advances at its slowest shard's rate" % depth1, "note_balanced": "balanced_*: the same with the images dealt by lsd_shard_balanced (costs = the cycles each image took in the full run before: a site's maps cost about the same from step to step)", "note": "each contiguous shard of the %d images run alone on this one GPU (best of 2); "
                                             "the sharded step takes at least its slowest shard: the region stage gives one CU per image, so a shard "
                                             "cannot finish before its heaviest image does" % n_total}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -30,7 +30,8 @@ __device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 
 template <int HS>
 __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
                                               const double* __restrict__ taps_g, int W, int H, int w, int h, int gp,
-                                              double sca, int tapR, int IWp, int IHmax, unsigned gx, unsigned gy, unsigned tiles) {
+                                              double sca, int tapR, int IWp, int IHmax, unsigned gx, unsigned gy, unsigned tiles,
+                                              uint8_t* __restrict__ clr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int hSize = HS > 0 ? HS : 2 * tapR + 1;
     double* aux = reinterpret_cast<double*>(smem);                // [IHmax][TW]
@@ -50,6 +51,19 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     const uint8_t* src = in + img * (size_t)W * H;
     double* dst = out + img * (size_t)gp * h;                     // rows padded to gp doubles (128-byte aligned rows for K2)
 
+    if (clr) {
+        // lineIm = Mat::zeros (myLSD.cpp:215), fused: this kernel is bound by its fp64 filter and LDS staging, its store path idles, so every
+        // tile clears the t-th of its image's `tiles per image` contiguous shares of the raster on the way (16 bytes per lane and store,
+        // non-temporal; launch_gauss only passes the raster when its size and address are multiples of 16).  As a kernel of its own the
+        // clear took 0.44 ms of the bench step.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned tpi = gx * gy, ti = t % tpi;
+        const size_t units = ((size_t)W * H) >> 4;
+        const size_t a = units * ti / tpi, e = units * (ti + 1) / tpi;
+        u32x4* const v = reinterpret_cast<u32x4*>(clr + img * (size_t)W * H);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (size_t u = a + tid; u < e; u += NT) __builtin_nontemporal_store(z, &v[u]);
+    }
     const int Xl = min(X0 + TW - 1, w - 1), Yl = min(Y0 + TH - 1, h - 1);
     const int c0 = centre_of(X0, sca) - tapR, c1 = centre_of(Xl, sca) + tapR;
     const int r0 = centre_of(Y0, sca) - tapR, r1 = centre_of(Yl, sca) + tapR;
@@ -201,7 +215,8 @@ __global__ __launch_bounds__(256) void k_remap_inplace(uint8_t* __restrict__ img
     }
 }
 
-void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
+// clr: lineIm to be cleared on the way (null: none; the caller has checked that every image's raster is a whole number of 16-byte words)
+void launch_gauss(const Geom& g, const Buffers& b, int n, uint8_t* clr, hipStream_t s) {
     const int span = (int)floor((TW - 1) / g.sca) + 2;            // bound on centre(X0+31) - centre(X0) + 1
     const int IWmax = span + 2 * g.tapR + 1;
     int IWp = ((IWmax + 3) & ~3) + 8;                             // + the alignment slack of the word-wise staging and of the x-pass's 5-word reads
@@ -214,7 +229,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned gx = (g.w + TW - 1) / TW, gy = (g.h + TH - 1) / TH, tiles = gx * gy * (unsigned)n;
     hipLaunchKernelGGL(kern, dim3(((tiles + 7u) >> 3) * 8u), dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.gp, g.sca,
-                       g.tapR, IWp, IHmax, gx, gy, tiles);
+                       g.tapR, IWp, IHmax, gx, gy, tiles, clr);
 }
 
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {

@@ -32,7 +32,7 @@ __device__ __forceinline__ int bin_of(double m, double zoom, int pseBin) {
 
 __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
                                               const unsigned long long* __restrict__ maxbits,
-                                              uint32_t* __restrict__ ord, uint16_t* __restrict__ ordv,
+                                              uint32_t* __restrict__ ord,
                                               int32_t* __restrict__ nb, uint32_t* __restrict__ kept_px, uint32_t* __restrict__ kept_v32,
                                               int npx, int pseBin) {
     extern __shared__ uint32_t hist[];                             // [SWAVES][pseBin] then [SWAVES] scratch
@@ -40,7 +40,6 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
     const size_t img = blockIdx.x;
     const double* m = mag + img * (size_t)npx;
     uint32_t* o = ord + img * (size_t)npx;
-    uint16_t* ov = ordv + img * (size_t)npx;
     uint32_t* kp = kept_px + img * (size_t)npx;                    // the kept pixels in raster order, wave s's from kp[beg_s] on
     uint16_t* kv = reinterpret_cast<uint16_t*>(kept_v32 + img * (size_t)npx);   // ... and their bin values
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -132,8 +131,7 @@ __global__ __launch_bounds__(SNT) void k_sort(const double* __restrict__ mag,
             const uint32_t start = myh[b];
             if (act) {
                 const uint32_t r = start + (uint32_t)__builtin_popcountll(peers & lt);
-                o[r] = pv[j];
-                ov[r] = (uint16_t)vv[j];
+                o[r] = pv[j];                                  // (the bin values themselves are not kept: k_ordv recomputes them for the debug fetch)
                 if (((peers >> lane) >> 1) == 0ull) myh[b] = start + (uint32_t)__builtin_popcountll(peers);   // the group's last lane
             }
         }
@@ -181,13 +179,25 @@ void launch_order(const Buffers& b, int n, int npx, const long long* hist, hipSt
     hipLaunchKernelGGL(k_order, dim3(1), dim3(256), 0, s, b.nb, hist, b.order, n, npx);
 }
 
+// Debug fetch (LSD_DBG_ORDER_VAL): the bin value of every entry of one image's sorted list, recomputed with the sort's own bin_of()
+// (the sort does not store them: the region stage never reads them, and the scattered 2-byte stores cost a 32-byte sector each).
+__global__ __launch_bounds__(256) void k_ordv(const double* __restrict__ mag, const unsigned long long* __restrict__ maxbits, const uint32_t* __restrict__ ord,
+                                              uint16_t* __restrict__ out, int count, int pseBin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double maxGrad = __longlong_as_double((long long)maxbits[0]);
+    if (i < count && maxGrad > 0) out[i] = (uint16_t)bin_of(mag[ord[i]], 1.0 * pseBin / maxGrad, pseBin);
+}
+void launch_ordv(const double* mag, const unsigned long long* maxbits, const uint32_t* ord, uint16_t* out, int count, int pseBin, hipStream_t s) {
+    if (count > 0) hipLaunchKernelGGL(k_ordv, dim3((count + 255) / 256), dim3(256), 0, s, mag, maxbits, ord, out, count, pseBin);
+}
+
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const size_t lds = ((size_t)SWAVES * g.pseBin + SWAVES) * sizeof(uint32_t);
     // 16 x 1024 bins x 4 B is just over the 64 KiB default; gfx950 has 160 KiB of LDS per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     // (the kept lists live in the region stage's seed arrays, which that stage fills at its start: they are free until then)
-    hipLaunchKernelGGL(k_sort, dim3(n), dim3(SNT), lds, s, b.mag, b.maxbits, b.ord, b.ordv, b.nb, b.seedidx, b.seedpos, g.npx, g.pseBin);
+    hipLaunchKernelGGL(k_sort, dim3(n), dim3(SNT), lds, s, b.mag, b.maxbits, b.ord, b.nb, b.seedidx, b.seedpos, g.npx, g.pseBin);
 }
 
 }  // namespace lsdhip

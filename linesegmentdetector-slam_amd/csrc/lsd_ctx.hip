@@ -54,7 +54,6 @@ struct lsd_ctx {
     int* rnum = nullptr;
     int mcap = 16384;
     int gcap = 8192;
-    uint16_t* ordv = nullptr;
     unsigned long long* maxbits = nullptr;
     int32_t *nb = nullptr, *nseed = nullptr;
     long long* stats = nullptr;
@@ -295,7 +294,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         const size_t tot = nn * pp;
         HIPCHK(c, re_alloc(&c->gauss, nn * gg)); HIPCHK(c, re_alloc(&c->mag, tot)); HIPCHK(c, re_alloc(&c->deg, tot));
         HIPCHK(c, re_alloc(&c->sc, tot));
-        HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot)); HIPCHK(c, re_alloc(&c->ordv, tot));
+        HIPCHK(c, re_alloc(&c->pw, tot)); HIPCHK(c, re_alloc(&c->epochmap, tot)); HIPCHK(c, re_alloc(&c->ord, tot));
         HIPCHK(c, re_alloc(&c->spill, ws * pp)); HIPCHK(c, re_alloc(&c->gcopy, ws * pp)); HIPCHK(c, re_alloc(&c->wmeta, ws * (size_t)c->mcap));
         HIPCHK(c, re_alloc(&c->stamps, ws * tm_words(pp))); HIPCHK(c, re_alloc(&c->seedidx, tot)); HIPCHK(c, re_alloc(&c->seedpos, tot)); HIPCHK(c, re_alloc(&c->tepoch, nn * (pp / 16 + 4096)));
         HIPCHK(c, hipMemset(c->stamps, 0, ws * tm_words(pp) * sizeof(uint32_t)));
@@ -334,7 +333,7 @@ static int ensure_workspace(lsd_ctx* c, size_t n, size_t npx, size_t gpx, int ma
     if (st != LSD_OK) {
         (void)hipGetLastError();                                      // the failed hipMalloc is sticky otherwise
         void** ptrs[] = {(void**)&c->gauss, (void**)&c->mag, (void**)&c->deg, (void**)&c->sc, (void**)&c->pw, (void**)&c->epochmap,
-                         (void**)&c->ord, (void**)&c->ordv, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
+                         (void**)&c->ord, (void**)&c->spill, (void**)&c->gcopy, (void**)&c->wmeta, (void**)&c->stamps,
                          (void**)&c->seedidx, (void**)&c->seedpos, (void**)&c->tepoch, (void**)&c->slist, (void**)&c->pend, (void**)&c->order, (void**)&c->xq, (void**)&c->sets,
                          (void**)&c->maxbits, (void**)&c->nb, (void**)&c->nseed, (void**)&c->stats, (void**)&c->rnum, (void**)&c->seeds,
                          (void**)&c->recs, (void**)&c->recs_scaled};
@@ -449,7 +448,7 @@ void lsd_destroy(lsd_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->sets, c->wmeta, c->rnum, c->ordv,
+    void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->sets, c->wmeta, c->rnum,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
                     c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf, c->ga_cnt, c->ga_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -542,7 +541,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
     b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb;
-    b.ord = c->ord; b.ordv = c->ordv; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
+    b.ord = c->ord; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
     b.tm_stride = 4 * ((g.w + 7) >> 3) * ((g.h + 7) >> 3);
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
     b.recs = c->recs; b.recs_scaled = c->recs_scaled; b.counts = d_counts; b.lines = d_lines; b.line_im = d_line_ims;
@@ -568,8 +567,11 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * n, s));
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (d_line_ims) launch_clear(d_line_ims, (size_t)n * cols * rows, c->num_cus, s);        // Mat::zeros, myLSD.cpp:215 (inside the event window: part of "gauss")
-    launch_gauss(g, b, n, s);
+    // Mat::zeros, myLSD.cpp:215: the Gaussian's tiles clear lineIm on the way where the raster is made of whole 16-byte words; else a
+    // kernel of its own does (inside the event window either way: part of "gauss")
+    const bool fused_clear = d_line_ims && (((size_t)cols * rows) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_line_ims) & 15) == 0;
+    if (d_line_ims && !fused_clear) launch_clear(d_line_ims, (size_t)n * cols * rows, c->num_cus, s);
+    launch_gauss(g, b, n, fused_clear ? d_line_ims : nullptr, s);
     if (b.in_rw) launch_remap_writeback(g, b, n, s);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_GRAD) launch_gradient(g, b, n, s);
@@ -779,7 +781,17 @@ int lsd_debug_fetch(lsd_ctx* c, int image, int what, void* out, size_t bytes) {
         case LSD_DBG_ORDER_VAL:
             HIPCHK(c, hipMemcpy(&nbv, c->nb + image, 4, hipMemcpyDeviceToHost));
             if (what == LSD_DBG_ORDER) { src = c->ord + off; need = (size_t)nbv * 4; }
-            else { src = c->ordv + off; need = (size_t)nbv * 2; }
+            else {                                                    // the bin values are recomputed on demand (k_sort.hip: k_ordv)
+                if (bytes < (size_t)nbv * 2) return LSD_ERR_INVALID;
+                uint16_t* tmp = nullptr;
+                HIPCHK(c, hipMalloc(&tmp, (size_t)(nbv > 0 ? nbv : 1) * 2));
+                launch_ordv(c->mag + off, c->maxbits + image, c->ord + off, tmp, nbv, c->geom.pseBin, c->last_stream);
+                hipError_t e = hipStreamSynchronize(c->last_stream);
+                if (e == hipSuccess && nbv > 0) e = hipMemcpy(out, tmp, (size_t)nbv * 2, hipMemcpyDeviceToHost);
+                (void)hipFree(tmp);
+                HIPCHK(c, e);
+                return LSD_OK;
+            }
             break;
         case LSD_DBG_NB: src = c->nb + image; need = 4; break;
         case LSD_DBG_MAXGRAD: src = c->maxbits + image; need = 8; break;

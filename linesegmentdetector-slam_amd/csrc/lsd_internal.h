@@ -62,7 +62,6 @@ struct Buffers {
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
-    uint16_t* ordv;        // n x npx : bin values
     uint32_t* stamps;      // n x NW x tm_stride : per wave, the member masks of the tiles its cache has evicted (4 words per 8x8 tile: grow id, -, 64 bits)
     int tm_stride;         // words per wave of the above: 4 x tiles of the scaled image
     uint32_t* spill;       // n x NW x npx : region list beyond the LDS part
@@ -113,10 +112,11 @@ struct SeedRec {  // mirrors oracle's orc_seed
 };
 
 // launchers (each enqueues on `s`)
-void launch_gauss(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_gauss(const Geom& g, const Buffers& b, int n, uint8_t* clr, hipStream_t s);   // clr: lineIm to be cleared on the way, or null
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s);
 void launch_sort(const Geom& g, const Buffers& b, int n, hipStream_t s);
+void launch_ordv(const double* mag, const unsigned long long* maxbits, const uint32_t* ord, uint16_t* out, int count, int pseBin, hipStream_t s);   // debug fetch of the bin values
 void launch_order(const Buffers& b, int n, int npx, const long long* hist, hipStream_t s);   // hist: the last launch's counter records (cost history) or null
 // the region stage with 4 resp. 8 wavefronts per image (k_region.hip is compiled twice)
 void launch_region_w4(const Geom& g, const Buffers& b, int n, uint32_t id_base, hipStream_t s);
