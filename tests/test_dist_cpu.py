@@ -217,3 +217,29 @@ def test_bench_batch_generator(maps):
     assert set(np.unique(b)) <= {0, 1, 255}
     flip = bench.make_image(maps, 4, 512)                                         # i//4%4 == 1 -> left-right flip
     assert not np.array_equal(flip, bench.make_image(maps, 0, 512))
+
+
+def test_shard_balanced_deals_by_cost():
+    """lsd_shard_balanced (C ABI, no GPU needed): a permutation; rank r's contiguous shard of it (lsd_shard_range) ascending inside, and
+    the shards' costs far closer to each other than those of the plain contiguous split when the costs are skewed."""
+    import ctypes as C
+    import importlib
+    lsd = importlib.import_module("linesegmentdetector-slam_amd")
+    L = lsd.load_library()
+    rng = np.random.default_rng(1)
+    costs = (rng.pareto(2.0, 512) * 1e7 + 2e7).astype(np.int64)
+    costs[:40] *= 4                                               # (the heavy images at the front: what the bench batch looks like)
+    for world in (1, 2, 3, 4, 8):
+        perm = lsd.shard_balanced(costs, world)
+        assert sorted(perm.tolist()) == list(range(512))
+        bal, con = [], []
+        for r in range(world):
+            lo, hi = C.c_int(), C.c_int()
+            L.lsd_shard_range(512, world, r, C.byref(lo), C.byref(hi))
+            assert np.all(np.diff(perm[lo.value:hi.value]) > 0)
+            bal.append(int(costs[perm[lo.value:hi.value]].sum())); con.append(int(costs[lo.value:hi.value].sum()))
+        assert max(bal) <= max(1.15 * np.mean(bal), np.mean(bal) + costs.max())      # (the greedy deal's guarantee: mean + the largest single cost)
+        if world >= 4:
+            assert max(bal) < max(con)
+    with pytest.raises(lsd.LsdError):
+        lsd.shard_balanced(np.zeros(0, np.int64), 2)

@@ -1157,6 +1157,28 @@ def test_schedule_of_the_region_stage_changes_nothing(tun, maps, lsdmod, ctx):
         c.close()
 
 
+def test_cost_history_changes_the_order_not_the_result(maps, lsdmod, ctx):
+    """lsd_set_cost_history: the region stage starts a batch's images in the order of their cost in the context's previous call.  The same
+    96-image batch gives the same bytes with the hint (after a first call that records the costs) as without, and lsd_last_region_cycles
+    reports a cost for every image."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    batch = bench.make_batch(maps, 96, 1024, 140)
+    ref = ctx.run_batch(batch.copy())
+    c = lsdmod.Context(0)
+    try:
+        c.set_cost_history(True)
+        for rep in range(3):
+            got = c.run_batch(batch.copy())
+            assert all(a.tobytes() == b.tobytes() for a, b in zip(got, ref)), rep
+        cyc = c.last_region_cycles(96)
+        assert cyc.shape == (96,) and np.all(cyc > 0)
+        perm = lsdmod.shard_balanced(cyc, 4)
+        assert sorted(perm.tolist()) == list(range(96))
+    finally:
+        c.close()
+
+
 def test_batches_in_flight_on_several_contexts(maps, lsdmod, ctx):
     """Throughput mode (bench.py --pipeline): three batches in flight, one context and one stream each,
     help across workgroups off, so that the workgroups of one batch's region stage fill the CUs the other's finished images
