@@ -18,8 +18,12 @@ rows = [
     ("**`value`**", "**%.1f Gpix/s, %.1f ms per step, %.2f M lines/s** (%d lines per step)" % (j["value"] / 1e3, j["ms_per_step"], j["lines_per_s"] / 1e6, j["lines_per_step"])),
     ("the same with 128 timed steps (the drain of the steps in flight amortised)", "**%.1f Gpix/s, %.1f ms per step, %.2f M lines/s** (`%s`)" % (
         long_run["value"] / 1e3, long_run["ms_per_step"], long_run["lines_per_s"] / 1e6, os.path.relpath(lp, ROOT))) if long_run else ("long run", "n/a"),
-    ("one step at a time", "%.1f ms = %.1f Gpix/s; kernels K1 %.2f (incl. the lineIm clear) / K2 %.2f / K3 %.2f / K4 %.1f / K5 %.2f ms" % (
-        one["ms_per_step"], one["value"] / 1e3, k["gauss"], k["gradient"], k["sort"], k["region"], k["lines"])),
+    ("one step at a time", "%.1f ms = %.1f Gpix/s; kernels K1 %.2f (incl. the lineIm clear) / K2 %.2f / K3 %.2f / K4 %.1f / K5 %.2f ms: front end %.2f ms" % (
+        one["ms_per_step"], one["value"] / 1e3, k["gauss"], k["gradient"], k["sort"], k["region"], k["lines"], k["gauss"] + k["gradient"] + k["sort"] + k["lines"])),
+    ("… with the cost history of the previous step (`lsd_set_cost_history`: same maps again)", "%.1f ms = %.1f Gpix/s" % (
+        j["one_step_at_a_time_with_cost_history"]["ms_per_step"], j["one_step_at_a_time_with_cost_history"]["value"] / 1e3)) if j.get("one_step_at_a_time_with_cost_history") else ("cost history", "n/a"),
+    ("the front end inside the timed region (event to event, waits for a CU included)", "K1 %.0f / K2 %.0f / K3 %.0f / K5 %.0f ms" % tuple(
+        j["kernel_ms_in_timed_region"][x] for x in ("gauss", "gradient", "sort", "lines"))) if j.get("kernel_ms_in_timed_region") else ("front end in the timed region", "n/a"),
     ("`roofline` (K2)", "%.0f GB/s algorithmic = **%.3f** of 8 TB/s (launch %.3f ms); PMC traffic %s GB per launch; device copy in the same process %s GB/s" % (
         rf["achieved"], rf["frac"], rf["avg_launch_ms"], "%.2f" % (rf["traffic"] / 1e9) if rf.get("traffic") else "n/a", "%.0f" % rf["measured_copy_GBs"] if "measured_copy_GBs" in rf else "n/a")),
     ("K4 cycles per image", "alone (8 waves, help on): mean %.1f M, max %.1f M; timed region (%s): mean %.1f M, max %.1f M" % (
@@ -45,6 +49,9 @@ if p:
             "%s: slowest shard %.1f ms, fastest %.1f (%.2f x; %d in flight)" % (g, p[g]["pipelined_max_shard_ms_per_step"], p[g]["pipelined_min_shard_ms_per_step"], p[g]["pipelined_speedup"],
                                                                               p[g].get("pipelined_steps_in_flight", 8)) for g in ("2", "4", "8"))
         rows.append(("… in throughput mode (every rank keeps the same number of images in flight: 8 × N steps, at most 32)", thr))
+    if all("balanced_speedup" in p[g] for g in ("2", "4", "8")):
+        rows.append(("… with the cost-aware deal (`lsd_shard_balanced`)", "one step: " + " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["balanced_max_shard_ms"], p[g]["balanced_speedup"]) for g in ("2", "4", "8")) +
+                     ("; throughput mode: " + " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["pipelined_balanced_max_shard_ms_per_step"], p[g]["pipelined_balanced_speedup"]) for g in ("2", "4", "8")) if all("pipelined_balanced_speedup" in p[g] for g in ("2", "4", "8")) else "")))
 table = "| | |\n|---|---|\n" + "\n".join("| %s | %s |" % r for r in rows)
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
