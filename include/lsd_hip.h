@@ -105,8 +105,10 @@ int lsd_set_host_max_lines(lsd_ctx *ctx, int max_lines);
 int lsd_enqueue_batch_device(lsd_ctx *ctx, uint8_t *d_maps, int n, int cols, int rows,
                              const lsd_params *p, unsigned flags, uint8_t *d_line_ims,
                              lsd_line *d_lines, int max_lines, int32_t *d_counts, void *stream);
-/* Pre-sizes the workspace so that lsd_enqueue_batch_device never allocates: 105 B per scaled pixel on 4 wavefronts per image, 148 B on
- * 8 (lsd_set_region_waves, below; call it first), i.e. 40 / 56 MB per 2048 x 2048 map at sca 0.3 -- 20 / 29 GB for 512 of them. */
+/* Pre-sizes the workspace so that lsd_enqueue_batch_device never allocates: 103 B per scaled pixel on 4 wavefronts per image, 146 B on
+ * 8 (lsd_set_region_waves, below; call it first), i.e. 39 / 55 MB per 2048 x 2048 map at sca 0.3 -- 20.0 / 28.2 GB for 512 of them
+ * (tools/workspace_size.py).  The workspace is sized for the helper pool of the default help setting even while help is off, so that
+ * lsd_set_region_help never makes a later enqueue allocate. */
 int lsd_reserve(lsd_ctx *ctx, int n, int cols, int rows);
 /* Blocks until the stream used by the last enqueue is idle. */
 int lsd_synchronize(lsd_ctx *ctx);

@@ -20,12 +20,16 @@ from oracle import oracle  # noqa: E402
 
 SMALL = [2995, 1759, 6382, 10647, 18262, 27264, 38359, 40212, 45813, 48150, 54902, 55115, 56831, 58631]
 BIG = [297]
+# ... and the one image of the campaigns with an NFA comparison inside what an ulp of exp / log10 / pow can move (margin 0.27: two hopeless
+# rectangles, 5 aligned pixels of 656, whose tails are 1 - 1e-15, so that logNFA = -logNT to the last place): both builds decide alike on
+# it -- kept so that a libm (or a change of the device routines) that decides otherwise shows up
+NEAR = [705]
 NAMES = {2995: "tie_a", 1759: "tie_b"}                     # (the two fixtures of round 3 keep their names)
 
 out, table = {}, {}
-for i, big in [(i, False) for i in SMALL] + [(i, True) for i in BIG]:
+for i, big in [(i, False) for i in SMALL] + [(i, True) for i in BIG] + [(i, True) for i in NEAR]:
     img, kw, _ = campaign_image(i, big)
-    name = NAMES.get(i, "%s%d" % ("big" if big else "img", i))
+    name = NAMES.get(i, "%s%d" % ("near" if i in NEAR else "big" if big else "img", i))
     a = oracle.lsd(img.copy(), debug=True, **kw)
     b = oracle.lsd(img.copy(), debug=True, _lib=oracle.lib_cr(), **kw)
     out[name] = img

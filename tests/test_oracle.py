@@ -258,7 +258,11 @@ def test_libm_tie_images_document_the_one_caveat(name, oracle):
     assert len(b["lines"]) == t["lines_cr"]                           # what the HIP path gives too (test_parity_gpu.py)
     assert len(a["lines"]) == t["lines_glibc"], "this libm rounds differently from the glibc the campaign ran against"
     assert int((a["dbg"]["used"] != b["dbg"]["used"]).sum()) == t["used_diff"]
-    assert int((a["lineIm"] != b["lineIm"]).sum()) == t["lineim_diff"] and t["used_diff"] + t["lineim_diff"] > 0
+    assert int((a["lineIm"] != b["lineIm"]).sum()) == t["lineim_diff"]
+    if name.startswith("near"):                                       # (an NFA comparison inside the libms' noise: the two builds decide alike on it)
+        assert t["used_diff"] == 0 and t["lineim_diff"] == 0 and a["dbg"]["nfa_min_gap"] < 1.0
+        return
+    assert t["used_diff"] + t["lineim_diff"] > 0
     sa, sb = a["dbg"]["seeds"], b["dbg"]["seeds"]
     key = lambda s: (int(s["order_idx"]), int(s["num"]), int(s["final_num"]), int(s["outcome"]))
     first = next((i for i, (x, y) in enumerate(zip(sa, sb)) if key(x) != key(y)), None)

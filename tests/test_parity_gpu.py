@@ -1332,7 +1332,8 @@ def test_libm_tie_images_equal_the_correctly_rounded_restatement(name, lsdmod, c
         assert np.array_equal(seeds[f], d["seeds"][f]), f
     assert np.array_equal(seeds["logNFA"], d["seeds"]["logNFA"])      # every NFA value, to the bit
     g = oracle.lsd(img.copy(), debug=True, **kw)                      # ... and differs from the glibc-built one (the caveat)
-    assert not (np.array_equal(used, g["dbg"]["used"]) and np.array_equal(im, g["lineIm"]))
+    same = np.array_equal(used, g["dbg"]["used"]) and np.array_equal(im, g["lineIm"])
+    assert same == name.startswith("near")                            # (near*: an NFA comparison inside the libms' noise on which both builds agree)
 
 
 def test_watchdog_failure_path_is_reported_not_fatal(maps, lsdmod, ctx):
