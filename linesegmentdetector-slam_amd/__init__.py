@@ -461,6 +461,7 @@ class Context:
                           "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
                          [int(x) for x in v]))
             d["set_answers"], d["sets_founded"] = int(v[41]), int(v[42])   # evaluations answered by a certified uniform set / sets founded (k_region.hip)
+            d["cycles_nfa_count"], d["nfa_tail_iters"] = int(v[43]), int(v[44])   # developer build: cycles of the NFA's pixel count, iterations of its tail sum
             d["nfa_bracket_misses"] = int(v[40])   # stopping tests of the NFA's tail left to the correctly rounded pow / log10 (an image the watchdog gave up keeps its record here instead)
             # how close RectangleImprover's comparisons came to a tie, as margins (distance of the operands over what an ulp of exp / log10 /
             # pow can move them; k_region.hip: improve()): smallest for a logNFA compared with 0, smallest for two compared NFA values (inf: none seen)

@@ -21,16 +21,15 @@ __device__ __forceinline__ int reflect_idx(int j, int lim) {  // myLSD.cpp:436-4
     return j;
 }
 
-__device__ __forceinline__ int centre_of(int x, double sca) {  // myLSD.cpp:428 / :460
-    return cvt_x86(floor(x / sca + 0.5));
-}
+// centre_of(x) = (int)floor(x / sca + 0.5) (myLSD.cpp:428 / :460) comes from a table the host fills with exactly that expression
+// (lsd_ctx.hip: ensure_tables): an fp64 division per use was a fifth of this kernel's vector instructions.
 
 // HS > 0: the tap count is a compile-time constant (17 for the reference's sca = 0.3, sig = 0.6): the x-pass keeps its
 // column's taps in registers and both passes are fully unrolled.  HS == 0: any tap count.
 template <int HS>
 __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, double* __restrict__ out,
-                                              const double* __restrict__ taps_g, int W, int H, int w, int h, int gp,
-                                              double sca, int tapR, int IWp, int IHmax, unsigned gx, unsigned gy, unsigned tiles,
+                                              const double* __restrict__ taps_g, const int* __restrict__ centre_of, int W, int H, int w, int h, int gp,
+                                              int tapR, int IWp, int IHmax, unsigned gx, unsigned gy, unsigned tiles,
                                               uint8_t* __restrict__ clr) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int hSize = HS > 0 ? HS : 2 * tapR + 1;
@@ -65,8 +64,8 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
         for (size_t u = a + tid; u < e; u += NT) __builtin_nontemporal_store(z, &v[u]);
     }
     const int Xl = min(X0 + TW - 1, w - 1), Yl = min(Y0 + TH - 1, h - 1);
-    const int c0 = centre_of(X0, sca) - tapR, c1 = centre_of(Xl, sca) + tapR;
-    const int r0 = centre_of(Y0, sca) - tapR, r1 = centre_of(Yl, sca) + tapR;
+    const int c0 = centre_of[X0] - tapR, c1 = centre_of[Xl] + tapR;
+    const int r0 = centre_of[Y0] - tapR, r1 = centre_of[Yl] + tapR;
     const int IH = r1 - r0 + 1;
 
     for (int i = tid; i < 3 * hSize; i += NT) taps[i] = taps_g[i];
@@ -74,6 +73,14 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     // stage the source window as 32-bit words (window columns start at a0 = c0 rounded down to a multiple of 4): every
     // thread first issues all its loads (up to 16 words in flight), then remaps (myLSD.cpp:135-142) and stores to LDS
     const int a0 = c0 - (((c0 % 4) + 4) % 4);
+    // bytes == 1 -> 255, bytes == 255 -> 0 (myLSD.cpp:135-142) on the four bytes of a word, except where `keep` has a byte of ones
+    auto remap4 = [](uint32_t x, uint32_t keep) -> uint32_t {
+        uint32_t t1 = x ^ 0x01010101u, t2 = ~x;                   // zero bytes mark the two cases
+        t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);   // 0x80 in every byte that was zero
+        t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
+        const uint32_t m1 = (t1 | (t1 - (t1 >> 7))) & ~keep, m255 = (t2 | (t2 - (t2 >> 7))) & ~keep;   // 0x80 -> 0xff (no multiply)
+        return (x | m1) & ~m255;
+    };
     {
         // 32 word columns x 8 rows of threads: a thread keeps its word column and walks down the window 8 rows at a time, so the
         // column work (bounds, reflection, "column 0 keeps raw values") is done once and nothing is divided
@@ -81,6 +88,34 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
         uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
         const int DWp = IWp >> 2;
         const int tx = tid & 31, ty = tid >> 5;
+        // A window that lies inside the image, off its row 0 and column 0 (which keep their raw values, Q2), with aligned words: nothing
+        // is reflected and nothing exempt -- all but the tiles on the border (wave-uniform)
+        const bool plain = a0 >= 4 && a0 + 4 * DW <= W && r0 >= 1 && r1 < H && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+        if (plain) {
+            // whole groups of 8 window rows (one per row of threads) under wave-uniform conditions: a scalar row base plus one 32-bit
+            // lane offset; the window's last IH % 8 rows under a lane mask, once
+            const int nfull = IH >> 3, tail = IH & 7;
+            const uint8_t* const sb = src + (size_t)r0 * W + a0;
+            for (int cw = tx; cw < DW; cw += 32) {
+                const uint32_t voff = (uint32_t)ty * (uint32_t)W + 4u * (uint32_t)cw;
+                uint32_t* const t0 = tile32 + ty * DWp + cw;
+                for (int g0 = 0; g0 < nfull; g0 += 16) {
+                    uint32_t v[16];
+                    #pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        v[j] = 0u;
+                        if (g0 + j < nfull) v[j] = *reinterpret_cast<const uint32_t*>(sb + (size_t)(g0 + j) * 8u * (size_t)W + voff);
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        // words of 0 (free) and of 255s (unknown: 0 after the remap) are most of an occupancy map: where a whole wavefront
+                        // sees nothing else there is nothing to compute
+                        if (g0 + j < nfull) t0[(g0 + j) * 8 * DWp] = __ballot(v[j] + 1u > 1u) != 0ull ? remap4(v[j], 0u) : 0u;
+                    }
+                }
+                if (ty < tail) t0[nfull * 8 * DWp] = remap4(*reinterpret_cast<const uint32_t*>(sb + (size_t)nfull * 8u * (size_t)W + voff), 0u);
+            }
+        } else
         for (int cw = tx; cw < DW; cw += 32) {
             const int gx0 = a0 + 4 * cw;
             const bool fast_col = gx0 >= 0 && gx0 + 3 < W;        // the whole word lies inside the image
@@ -111,18 +146,9 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
                 for (int j = 0; j < 16; j++) {
                     const int r = rb + ty + 8 * j;
                     if (r < IH) {
+                        // row 0 and column 0 keep their raw values (Q2)
                         const uint32_t x = v[j];
-                        uint32_t o = 0u;                          // (a word of zeros -- unknown cells, most of an occupancy map -- stays zeros)
-                        if (x != 0u) {
-                            // bytes == 1 -> 255, bytes == 255 -> 0 (myLSD.cpp:135-142); row 0 and column 0 keep their raw values (Q2)
-                            uint32_t t1 = x ^ 0x01010101u, t2 = ~x;   // zero bytes mark the two cases
-                            t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
-                            t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
-                            const uint32_t keep = reflect_idx(r0 + r, H) == 0 ? 0xffffffffu : colkeep;
-                            const uint32_t m1 = ((t1 >> 7) * 255u) & ~keep, m255 = ((t2 >> 7) * 255u) & ~keep;
-                            o = (x | m1) & ~m255;
-                        }
-                        tile32[r * DWp + cw] = o;
+                        tile32[r * DWp + cw] = x != 0u ? remap4(x, reflect_idx(r0 + r, H) == 0 ? 0xffffffffu : colkeep) : 0u;
                     }
                 }
             }
@@ -134,7 +160,7 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     const int X = tid & (TW - 1);
     const int gX = X0 + X;
     {
-        const int cb = centre_of(gX, sca) - tapR - a0;            // first tap's column inside the window
+        const int cb = (gX < w ? centre_of[gX] : 0) - tapR - a0;            // first tap's column inside the window
         const double* ker = taps + (gX % 3) * hSize;
         if (gX < w) {
             if (HS > 0) {
@@ -180,15 +206,15 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
         for (int Y = tid / TW; Y < TH; Y += NT / TW) {
             const int gY = Y0 + Y;
             if (gY >= h) break;
-            const int rb = centre_of(gY, sca) - tapR - r0;
+            const int rb = centre_of[gY] - tapR - r0;
             const double* ker = taps + (gY % 3) * hSize;
             double v = 0;
             if (HS > 0) {
                 double a[HS > 0 ? HS : 1];
-                bool nz = false;
+                uint32_t bits = 0u;                            // (the x-pass writes sums of non-negative terms: +0.0 is the only zero)
                 #pragma unroll
-                for (int i = 0; i < HS; i++) { a[i] = aux[(rb + i) * TW + X]; nz |= a[i] != 0.0; }
-                if (__ballot(nz) != 0ull) {                    // (all zeros: the sum is +0.0, as in the x-pass)
+                for (int i = 0; i < HS; i++) { a[i] = aux[(rb + i) * TW + X]; bits |= (uint32_t)__double2hiint(a[i]) | (uint32_t)__double2loint(a[i]); }
+                if (__ballot(bits != 0u) != 0ull) {                    // (all zeros: the sum is +0.0, as in the x-pass)
                     #pragma unroll
                     for (int i = 0; i < HS; i++) v += a[i] * ker[i];
                 }
@@ -228,7 +254,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, uint8_t* clr, hipStrea
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const unsigned gx = (g.w + TW - 1) / TW, gy = (g.h + TH - 1) / TH, tiles = gx * gy * (unsigned)n;
-    hipLaunchKernelGGL(kern, dim3(((tiles + 7u) >> 3) * 8u), dim3(NT), lds, s, b.in, b.gauss, b.taps, g.W, g.H, g.w, g.h, g.gp, g.sca,
+    hipLaunchKernelGGL(kern, dim3(((tiles + 7u) >> 3) * 8u), dim3(NT), lds, s, b.in, b.gauss, b.taps, b.centres, g.W, g.H, g.w, g.h, g.gp,
                        g.tapR, IWp, IHmax, gx, gy, tiles, clr);
 }
 

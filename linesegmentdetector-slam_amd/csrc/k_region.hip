@@ -143,7 +143,7 @@ struct RCtx {
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
        ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_SETHIT, ST_SETNEW, ST_COUNT };
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_SETHIT, ST_SETNEW, ST_NFACNT, ST_NFAITER, ST_COUNT };
 static_assert(ST_TOTAL == kStatTotalWord, "lsd_last_region_cycles reads this word");
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
@@ -1182,6 +1182,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
     const double k2 = (vy2 - vy3) / (vx2 - vx3);
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
     int all = 0, ali = 0;
+    [[maybe_unused]] const long long t00 = NOW();
     // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
     int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave));
     int* const s_lo = s_incl + 64;
@@ -1226,6 +1227,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
             ali += __builtin_popcountll(ballot64(hit));
         }
     }
+    PSTAT(ST_NFACNT, NOW() - t00);
     if (all == 0 || ali == 0) return -logNT;                                       // :1019-1022
     const double logp = c.ptab[rec.pk * 3 + 0], log10p = c.ptab[rec.pk * 3 + 1], log1mp = c.ptab[rec.pk * 3 + 2];
     if (all == ali) return -logNT - all * log10p;                                  // :1023-1026
@@ -1251,6 +1253,7 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
         const double multTerm = binTerm * proTerm;
         term *= multTerm;
         binTail += term;
+        DSTAT(ST_NFAITER, 1);
         if (binTerm < 1) {
             // err < tole * |-log10(binTail) - logNT| * binTail ?  (:1052-1053)  Every operation of the two sides is monotone in the value
             // of pow resp. log10, so the sides at the ends of the brackets enclose the sides at the correctly rounded values.

@@ -71,6 +71,7 @@ struct lsd_ctx {
     bool hcap_lineim = false;
     // tables
     double *d_taps = nullptr, *d_lgamma = nullptr, *d_ptab = nullptr;
+    int* d_centres = nullptr;
     int lg_count = 0;                   // entries of d_lgamma
     bool cost_history = false;          // lsd_set_cost_history: the region stage takes the images in the order of their cost in the last launch
     int hist_n = 0;                     // images of the launch whose counter records are in `stats` (0: none)
@@ -214,9 +215,12 @@ static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStre
     if (!c->d_ptab) {
         HIPCHK(c, hipMalloc(&c->d_ptab, sizeof(double) * kPTable * 3));
         HIPCHK(c, hipMalloc(&c->d_taps, sizeof(double) * 3 * (2 * kMaxTapRadius + 1)));
+        HIPCHK(c, hipMalloc(&c->d_centres, sizeof(int) * kCentreCount));
     }
     std::vector<double> taps;
     gauss_taps(p->sca, p->sig, g.tapR, taps);
+    std::vector<int> centres(kCentreCount);                         // myLSD.cpp:428 / :460, the host's own division and rounding
+    for (int x = 0; x < kCentreCount; x++) centres[x] = cvt_x86(floor(x / p->sca + 0.5));
     double pt[kPTable * 3];
     double pr = g.aliPro;
     for (int k = 0; k < kPTable; k++) {
@@ -229,6 +233,7 @@ static int ensure_tables(lsd_ctx* c, const lsd_params* p, const Geom& g, hipStre
     if (c->done_valid) HIPCHK(c, hipEventSynchronize(c->ev_done));
     HIPCHK(c, hipMemcpy(c->d_taps, taps.data(), sizeof(double) * taps.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_ptab, pt, sizeof(pt), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_centres, centres.data(), sizeof(int) * kCentreCount, hipMemcpyHostToDevice));
     c->tab_params = *p;
     c->tab_valid = true;
     c->tapR = g.tapR;
@@ -450,7 +455,7 @@ void lsd_destroy(lsd_ctx* c) {
     (void)hipDeviceSynchronize();
     void* ptrs[] = {c->gauss, c->mag, c->deg, c->sc, c->recs, c->recs_scaled, c->pw, c->epochmap, c->ord, c->spill, c->gcopy, c->stamps, c->seedidx, c->seedpos, c->tepoch, c->slist, c->pend, c->order, c->xq, c->sets, c->wmeta, c->rnum,
                     c->maxbits, c->nb, c->nseed, c->stats, c->seeds, c->h_in, c->h_lineim, c->h_lines, c->h_counts,
-                    c->d_taps, c->d_lgamma, c->d_ptab, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf, c->ga_cnt, c->ga_slab};
+                    c->d_taps, c->d_lgamma, c->d_ptab, c->d_centres, c->mc_claim, c->mc_fa, c->mc_fb, c->mc_ctl, c->mc_in, c->mc_out, c->oc_in, c->oc_out, c->mt_buf, c->ga_cnt, c->ga_slab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -559,7 +564,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
         b.npool = b.xq ? pool_for(c, n) : 0;
     }
-    b.taps = c->d_taps; b.lgamma = c->d_lgamma; b.lg_count = c->lg_count; b.ptab = c->d_ptab;
+    b.taps = c->d_taps; b.centres = c->d_centres; b.lgamma = c->d_lgamma; b.lg_count = c->lg_count; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
 
     HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));

@@ -7,6 +7,7 @@
 namespace lsdhip {
 
 constexpr double kPi = 3.14159265358979323846;  // == 4.0*atan(1.0), myLSD.cpp:9
+constexpr int kCentreCount = 32768;             // scaled coordinates are below 32766 (make_geom)
 constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per phase kernel
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries every context starts with; it grows to w*h + 2 (the largest
 constexpr int kLgTableMax = 1 << 23;            //    pixel count a rectangle can have, + 1), up to this many
@@ -97,6 +98,7 @@ struct Buffers {
     int max_lines;
     // tables
     const double* taps;    // 3 x (2*tapR+1)
+    const int* centres;    // kCentreCount: (int)floor(x / sca + 0.5) for every scaled coordinate x (K1's window centres, myLSD.cpp:428 / :460)
     const double* lgamma;  // lg_count entries: LogGammaCalculator(i) from the host libm
     int lg_count;
     const double* ptab;    // kPTable x 3 : log(p), log10(p), log(1-p)

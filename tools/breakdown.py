@@ -34,12 +34,12 @@ st = [ctx.fetch(i, lsd.DBG_STATS, wh) for i in range(n)]
 tot = np.array([x["cycles_total"] for x in st], np.float64)
 wave_cycles = tot.sum() * waves
 print("images %d, waves %d: per-image cycles mean %.1fM max %.1fM; wave-cycles total %.1fG" % (n, waves, tot.mean() / 1e6, tot.max() / 1e6, wave_cycles / 1e9))
-keys = ["cycles_eval", "cycles_grow", "cycles_tiles", "cycles_sums", "cycles_rect", "cycles_refine", "cycles_nfa", "cycles_mark", "cycles_small", "cycles_refill", "cycles_select", "cycles_commit",
+keys = ["cycles_eval", "cycles_grow", "cycles_tiles", "cycles_sums", "cycles_rect", "cycles_refine", "cycles_nfa", "cycles_nfa_count", "cycles_mark", "cycles_small", "cycles_refill", "cycles_select", "cycles_commit",
         "cycles_wait", "wait_noslot", "wait_noseed", "cycles_eval_at_cursor"]
 for k in keys:
     v = sum(x[k] for x in st)
     print("  %-22s %7.2fG  %5.1f %%" % (k, v / 1e9, 100.0 * v / wave_cycles))
-for k in ("grow_calls", "grown_px", "batches", "tile_fetches", "small_steps", "small_bails", "nfa_calls", "seeds", "spec_redos", "spec_discards", "exact_angle_evals", "refill_rounds", "requeued_ahead"):
+for k in ("grow_calls", "grown_px", "batches", "tile_fetches", "small_steps", "small_bails", "nfa_calls", "nfa_tail_iters", "seeds", "spec_redos", "spec_discards", "exact_angle_evals", "refill_rounds", "requeued_ahead"):
     print("  %-22s %d" % (k, sum(x[k] for x in st)))
 b = sum(x["batches"] for x in st); g = sum(x["cycles_grow"] for x in st)
 print("cycles per grow() batch: %.0f; grown px per batch %.2f; px per grow %.1f" % (g / max(b, 1), sum(x["grown_px"] for x in st) / max(b, 1), sum(x["grown_px"] for x in st) / max(1, sum(x["grow_calls"] for x in st))))
