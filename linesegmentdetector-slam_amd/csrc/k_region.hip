@@ -1139,22 +1139,25 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
 // LogGammaCalculator (:882-924): a look-up in the host-computed table (lsd_ctx.hip sizes it for every pixel count a rectangle of
 // the image can have; only images of more than kLgTableMax scaled pixels can get past it, and then with the device's own log / sinh / pow)
 // ---------------------------------------------------------------------------------------------
-__device__ double log_gamma_dev(const RCtx& c, int x) {
-    if (x >= 0 && x < c.lg_count) return c.lgamma[x];
+__device__ __forceinline__ double log_gamma_dev(const double* lgamma, int lg_count, int x) {
+    if (x >= 0 && x < lg_count) return lgamma[x];
     const double xd = x;
     return 0.918938533204673 + (xd - 0.5) * log(xd) - xd +
            0.5 * xd * log(xd * sinh(1.0 / xd) + 1.0 / (810 * pow(xd, 6.0)));
 }
 
 // ---------------------------------------------------------------------------------------------
-// RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated)
+// RectangleNFACalculator, myLSD.cpp:926-1059 (the full-image pass :940-945 is a no-op, not restated), in two parts: the pixel
+// count of the rectangle with all 64 lanes (:947-1017), and the value from the two counts (:1019-1058) -- scalar arithmetic that
+// RectangleImprover's five tries of a phase run side by side in five lanes (improve(), below).
 // ---------------------------------------------------------------------------------------------
-// host_only: the value is made of host-computed numbers alone (logNT, log10 p: the reference's own libm) -- no device-evaluated function
-__device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, bool& host_only) {
-    host_only = true;
+// Returns `all`; ali[q] = pixels of the rectangle whose level-line angle is within prec[q] of the rectangle's (NP > 1: the tries of
+// a phase that halves p share the rectangle and differ in the precision only).
+template <int NP>
+__device__ __forceinline__ int nfa_count(const RCtx& c, const Rec& rec, const double (&prec)[NP], int (&ali)[NP]) {
     const int lane = c.lane, xLim = c.w, yLim = c.h;
-    const double logNT = c.logNT;
-    STAT(ST_NFA, 1);
+    STAT(ST_NFA, NP);
+    [[maybe_unused]] const long long t00 = NOW();
     double verX[4], verY[4];
     verX[0] = rec.x1 - rec.dy * rec.wid / 2.0;                                     // :949-956
     verX[1] = rec.x2 - rec.dy * rec.wid / 2.0;
@@ -1181,8 +1184,9 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
     const double k1 = (vy2 - vy1) / (vx2 - vx1);
     const double k2 = (vy2 - vy3) / (vx2 - vx3);
     const double k3 = (vy3 - vy0) / (vx3 - vx0);
-    int all = 0, ali = 0;
-    [[maybe_unused]] const long long t00 = NOW();
+    int all = 0;
+    #pragma unroll
+    for (int q = 0; q < NP; q++) ali[q] = 0;
     // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
     int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave));
     int* const s_lo = s_incl + 64;
@@ -1214,25 +1218,33 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
         all += tot;
         for (int t0 = 0; t0 < tot; t0 += 64) {                // flattened (column, row) pairs, 64 per step
             const int t = t0 + lane;
-            bool hit = false;
+            double df = 1e300;                                 // (no pixel: within no precision)
             if (t < tot) {
                 int ci = 0;                                    // smallest ci with s_incl[ci] > t
                 for (int step = 32; step >= 1; step >>= 1)
                     if (s_incl[ci + step - 1] <= t) ci += step;
                 const int ex = ci ? s_incl[ci - 1] : 0;
                 const int j = s_lo[ci] + (t - ex);
-                const double dv = c.deg[(size_t)j * xLim + s_x[ci]];
-                hit = angle_diff(rec.deg, dv) < rec.prec;                          // :1009-1013
+                df = angle_diff(rec.deg, c.deg[(size_t)j * xLim + s_x[ci]]);       // :1009-1011
             }
-            ali += __builtin_popcountll(ballot64(hit));
+            #pragma unroll
+            for (int q = 0; q < NP; q++) ali[q] += __builtin_popcountll(ballot64(df < prec[q]));   // :1012-1013
         }
     }
     PSTAT(ST_NFACNT, NOW() - t00);
-    if (all == 0 || ali == 0) return -logNT;                                       // :1019-1022
-    const double logp = c.ptab[rec.pk * 3 + 0], log10p = c.ptab[rec.pk * 3 + 1], log1mp = c.ptab[rec.pk * 3 + 2];
-    if (all == ali) return -logNT - all * log10p;                                  // :1023-1026
-    const double proTerm = rec.p / (1.0 - rec.p);
-    const double log1Coef = log_gamma_dev(c, all + 1) - log_gamma_dev(c, ali + 1) - log_gamma_dev(c, all - ali + 1);
+    return all;
+}
+
+// bit 0 of flags: the value is made of host-computed numbers alone (logNT, log10 p: the reference's own libm) -- no device-evaluated
+// function; bits 8..: stopping tests of the tail that the bracket (below) could not decide
+struct NfaVal { double v; int flags; };
+// Scalar code (every active lane for itself: improve() runs five at a time); p = the rectangle's p, pk the number of its halvings.
+__device__ __noinline__ NfaVal nfa_tail(int all, int ali, int pk, double p, double logNT, const double* ptab, const double* lgamma, int lg_count) {
+    if (all == 0 || ali == 0) return NfaVal{-logNT, 1};                            // :1019-1022
+    const double logp = ptab[pk * 3 + 0], log10p = ptab[pk * 3 + 1], log1mp = ptab[pk * 3 + 2];
+    if (all == ali) return NfaVal{-logNT - all * log10p, 1};                       // :1023-1026
+    const double proTerm = p / (1.0 - p);
+    const double log1Coef = log_gamma_dev(lgamma, lg_count, all + 1) - log_gamma_dev(lgamma, lg_count, ali + 1) - log_gamma_dev(lgamma, lg_count, all - ali + 1);
     const double log1Term = log1Coef + ali * logp + (all - ali) * log1mp;          // :1033
     // From here on the reference calls exp, log10 and pow.  What reaches the result -- the first term and the logarithm of the tail --
     // is evaluated correctly rounded (exp_g, log10_g: crmath.h); pow and log10 inside the loop only decide when the sum stops, and that
@@ -1241,10 +1253,10 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
     double term = exp_g(log1Term);
     const double eps = 2.2204e-16;
     if (fabs(term) < 100 * eps) {                                                  // :1037-1043
-        if (ali > all * rec.p) { host_only = false; return -log10_g(term) - logNT; }
-        return -logNT;
+        if (ali > all * p) return NfaVal{-log10_g(term) - logNT, 0};
+        return NfaVal{-logNT, 1};
     }
-    host_only = false;
+    int nslow = 0;
     double binTail = term;
     const double tole = 0.1;
     constexpr double kOcmlBracket = 0x1p-44, kTiny = 0x1p-1000;
@@ -1253,7 +1265,6 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
         const double multTerm = binTerm * proTerm;
         term *= multTerm;
         binTail += term;
-        DSTAT(ST_NFAITER, 1);
         if (binTerm < 1) {
             // err < tole * |-log10(binTail) - logNT| * binTail ?  (:1052-1053)  Every operation of the two sides is monotone in the value
             // of pow resp. log10, so the sides at the ends of the brackets enclose the sides at the correctly rounded values.
@@ -1269,76 +1280,100 @@ __device__ __forceinline__ double rect_nfa_impl(const RCtx& c, const Rec& rec, b
             if (err_hi < rhs_lo) stop = true;
             else if (!(err_lo < rhs_hi)) stop = false;
             else {
-                STAT(ST_NFASLOW, 1);                        // (stopping tests of the tail the bracket could not decide)
+                nslow++;                                    // (stopping tests of the tail the bracket could not decide)
                 const double err = term * ((1 - pow_g(multTerm, N)) / om - 1);
                 stop = err < tole * fabs(-log10_g(binTail) - logNT) * binTail;
             }
             if (stop) break;
         }
     }
-    return -log10_g(binTail) - logNT;
+    return NfaVal{-log10_g(binTail) - logNT, nslow << 8};
 }
 
-__device__ __forceinline__ double rect_nfa(const RCtx& c, const Rec& rec, bool& host_only) {
-    [[maybe_unused]] const long long t0 = NOW();
-    const double v = rect_nfa_impl(c, rec, host_only);
-    PSTAT(ST_TNFA, NOW() - t0);
-    return v;
-}
-
-// RectangleImprover, myLSD.cpp:1061-1158.  The reference's five hand-unrolled phases are walked by one
-// loop (step 0 = the initial evaluation, then 5 phases x 5 tries) so that the NFA code is inlined once.
+// RectangleImprover, myLSD.cpp:1061-1158: the initial evaluation, then five phases of five tries each.  Within a phase the tried
+// rectangles do not depend on the values found (only `best` does, and a phase starts from the best so far): the five pixel
+// counts are taken one after the other -- one pass for the phases that only halve p -- and the five values computed side by side.
 __device__ __noinline__ double improve(int cw_) {
     RCtx c = g_ctx[__builtin_amdgcn_readfirstlane(cw_)];
     c.lane = (int)(threadIdx.x & 63u);
+    const int lane = c.lane;
     const double delt = 0.5, delt2 = delt / 2.0;
     Rec& best = g_ws[c.wave].rec;                           // (the best rectangle so far stays in LDS: every lane writes the same values)
-    Rec r = best;
     double bestNFA = 0;
-    for (int step = 0; step <= 25; step++) {
-        const int phase = step == 0 ? -1 : (step - 1) / 5;
-        if (step > 0 && (step - 1) % 5 == 0) {              // phase boundary (:1078,:1093,:1108,:1126,:1144)
-            if (bestNFA > 0) break;
-            r = best;
-        }
-        bool eval = true;
-        if (phase == 0 || phase == 4) {                     // :1084-1092 / :1148-1156  halve p
-            r.p /= 2.0; r.prec = r.p * kPi; r.pk++;
-        } else if (phase == 1) {                            // :1097-1107  reduce width
-            if (r.wid - delt >= 0.5) r.wid -= delt; else eval = false;
-        } else if (phase == 2) {                            // :1112-1125  move one side
-            if (r.wid - delt >= 0.5) {
-                r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2;
-                r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2;
-                r.wid -= delt;
-            } else eval = false;
-        } else if (phase == 3) {                            // :1130-1143  move the other side
-            if (r.wid - delt >= 0.5) {
-                r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2;
-                r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2;
-                r.wid -= delt;
-            } else eval = false;
-        }
-        if (!eval) continue;
-        bool host_only;
-        const double v = rect_nfa(c, r, host_only);
-        // How close the two comparisons below come to a tie, as a MARGIN: the distance of the operands over the most the reference's
-        // libm (glibc: exp and pow within 1 ulp, log10 within 1 ulp of the correctly rounded values computed here) can move them apart.
-        // v = fl(-L - logNT) with L = log10(tail): |dL| <= 2^-51 |L| + 2^-53 (the tail's first term differs by an ulp), and the
-        // subtraction rounds to an ulp of max(|v|, logNT): noise(v) = 2^-51 |v + logNT| + 2^-52 (1 + max(|v|, logNT)).  A decision can come
-        // out differently on the two libms only where the margin is below 1 (tools/campaign.py enforces a floor of 2).  A value made of
-        // the host's numbers alone (-logNT - n log10 p: an exact 0 exists, w h = 6^4, p = 1/6, n = 10) is the reference's own.
+    [[maybe_unused]] const long long t0 = NOW();
+    // How close the comparisons below come to a tie, as a MARGIN: the distance of the operands over the most the reference's
+    // libm (glibc: exp and pow within 1 ulp, log10 within 1 ulp of the correctly rounded values computed here) can move them apart.
+    // v = fl(-L - logNT) with L = log10(tail): |dL| <= 2^-51 |L| + 2^-53 (the tail's first term differs by an ulp), and the
+    // subtraction rounds to an ulp of max(|v|, logNT): noise(v) = 2^-51 |v + logNT| + 2^-52 (1 + max(|v|, logNT)).  A decision can come
+    // out differently on the two libms only where the margin is below 1 (tools/campaign.py enforces a floor of 2).  A value made of
+    // the host's numbers alone (-logNT - n log10 p: an exact 0 exists, w h = 6^4, p = 1/6, n = 10) is the reference's own.
+    auto margins = [&](double v, bool host_only, bool first) {
         if (fabs(v) <= 1.7976931348623157e308) {
             const double nv = 0x1p-51 * fabs(v + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(v), c.logNT));
             if (!host_only) STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v) / nv));       // (v is compared with 0: :1075, :242)
-            if (step > 0 && v != bestNFA) {
+            if (!first && v != bestNFA) {
                 const double nb = 0x1p-51 * fabs(bestNFA + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(bestNFA), c.logNT));
                 STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA) / (nv + nb)));
             }
         }
-        if (step == 0) { bestNFA = v; if (v > 0) break; }   // :1075-1079
-        else if (v > bestNFA) { bestNFA = v; best = r; }
+    };
+    {   // :1075-1079
+        Rec r = best;
+        const double pr[1] = {r.prec};
+        int al[1];
+        const int all = nfa_count<1>(c, r, pr, al);
+        const NfaVal nv = nfa_tail(all, al[0], r.pk, r.p, c.logNT, c.ptab, c.lgamma, c.lg_count);
+        STAT(ST_NFASLOW, nv.flags >> 8);
+        margins(nv.v, (nv.flags & 1) != 0, true);
+        bestNFA = nv.v;
     }
+    // one try of phase ph (:1084-1092 / :1148-1156 halve p; :1097-1107 reduce width; :1112-1125 move one side; :1130-1143 the other)
+    auto next_try = [&](Rec& r, int ph) -> bool {
+        if (ph == 0 || ph == 4) { r.p /= 2.0; r.prec = r.p * kPi; r.pk++; return true; }
+        if (!(r.wid - delt >= 0.5)) return false;
+        if (ph == 2) { r.x1 -= r.dy * delt2; r.y1 += r.dx * delt2; r.x2 -= r.dy * delt2; r.y2 += r.dx * delt2; }
+        else if (ph == 3) { r.x1 += r.dy * delt2; r.y1 -= r.dx * delt2; r.x2 += r.dy * delt2; r.y2 -= r.dx * delt2; }
+        r.wid -= delt;
+        return true;
+    };
+    for (int ph = 0; ph < 5 && !(bestNFA > 0); ph++) {      // phase boundary (:1078,:1093,:1108,:1126,:1144)
+        // lane t < 5 keeps the counts of try t
+        int my_all = 0, my_ali = 0, my_pk = 0;
+        double my_p = 0.0;
+        bool my_eval = false;
+        Rec r = best;
+        if (ph == 0 || ph == 4) {
+            double pr[5];
+            int al[5];
+            #pragma unroll
+            for (int t = 0; t < 5; t++) pr[t] = r.p / (double)(2 << t) * kPi;      // p halved t + 1 times, exactly as next_try does it
+            const int all = nfa_count<5>(c, r, pr, al);
+            #pragma unroll
+            for (int t = 0; t < 5; t++)
+                if (lane == t) { my_all = all; my_ali = al[t]; my_pk = r.pk + t + 1; my_p = r.p / (double)(2 << t); my_eval = true; }
+        } else {
+            for (int t = 0; t < 5; t++) {
+                if (!next_try(r, ph)) continue;
+                const double pr[1] = {r.prec};
+                int al[1];
+                const int all = nfa_count<1>(c, r, pr, al);
+                if (lane == t) { my_all = all; my_ali = al[0]; my_pk = r.pk; my_p = r.p; my_eval = true; }
+            }
+        }
+        NfaVal nv{0.0, 0};
+        if (my_eval) nv = nfa_tail(my_all, my_ali, my_pk, my_p, c.logNT, c.ptab, c.lgamma, c.lg_count);
+        // the five values in the reference's order
+        r = best;
+        for (int t = 0; t < 5; t++) {
+            if (!next_try(r, ph)) continue;
+            const double v = rl(nv.v, t);
+            const int fl = __builtin_amdgcn_readlane(nv.flags, t);
+            STAT(ST_NFASLOW, fl >> 8);
+            margins(v, (fl & 1) != 0, false);
+            if (v > bestNFA) { bestNFA = v; best = r; }
+        }
+    }
+    PSTAT(ST_TNFA, NOW() - t0);
     return bestNFA;
 }
 
