@@ -2373,6 +2373,13 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     int ch_k0 = 0, ch_sx = 0, ch_sy = 0;                    // the wave's chunk: lane j < CH holds seed ch_k0 + j
     unsigned long long ch_pend = 0ull;                      // seeds of the chunk not handed to a group yet
     bool tw_small = false;                                  // the arena holds windows and small lists (not tiles / a region list)
+    bool gld = false;                                       // this lane's group waits for its window
+    unsigned long long gldm = 0ull;                         // bit 8g: group g waits for its window (wave-uniform)
+    int gld_age = 0;                                        // steps since the fetch
+#ifndef LSD_REGION_WINAGE
+#define LSD_REGION_WINAGE 2
+#endif
+    constexpr int kWinAge = LSD_REGION_WINAGE;              // steps the other groups take before a wave waits for the windows it fetched
     constexpr float kEpsS = 1.0e-5f;                        // kEpsU + the fp32 running sums of up to SCAP unit vectors
 
     int pend_k = -1, pend_slot = 0;                         // a full evaluation this wave has claimed and starts once its groups are done
@@ -2380,6 +2387,26 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     int nwait = 0, wd_f = -1;                               // looks that found nothing to do since the cursor was last seen to move (watchdog)
     long long xlast = 0;                                    // when this wave last looked at the help protocol
     int xwant = 0;                                          // 1: look at the help protocol, 2: ... and the cursor stands on a seed given away
+    // The windows fetched at the last refill are in LDS: seeds used meanwhile (:222) are skipped, the others start with their own pixel (:515-520)
+    auto window_arrived = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t sw = swin[7 * 16 + 7];              // (row 7, column 7 of the window: the seed's own word)
+        const bool used = gld && (sw & 3u) != 0u;
+        if (gld && !used) {
+            float s0, c0;
+            fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
+            gC = c0; gS = s0; gn = 1; gi = 0; gex = 1;
+            if (kq == 0) { swin[7 * 16 + 7] = sw | 1u; slst[0] = (7u << 4) | 7u; }
+        }
+        if (used) {
+            if (kq == 0) st_st(&rg.state[gk & (RW - 1)], R_SKIP);
+            gk = -1;
+        }
+        if (ballot64(used)) adv = true;
+        gld = false;
+        gldm = 0ull;
+        LT(ST_TREFILL);
+    };
     while (true) {
         int k = -1, slot = 0;
         bool spec = false;
@@ -2482,73 +2509,56 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                     }
                 }
             }
-            // idle groups take the next seeds of the chunk
+            // idle groups take the next seeds of the chunk: their windows are FETCHED here (straight into LDS, nothing waits) and the
+            // groups start at window_arrived() below, a step or two later -- the round trip to L2 / HBM runs beside the other groups' steps
             const unsigned long long idle0 = ~actm & 0x0101010101010101ull;     // bit 8g: group g is idle
             if (ch_pend && idle0) {
+                if (gldm) window_arrived();                // (one fetch in flight at a time)
                 unsigned long long idle = idle0;
                 const int snap = lds_ld(&s_epoch);         // before anything of usedMap is read for these seeds
                 wg_fence();
-                bool ld = false;
+                tw_small = true;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the windows' last stores have landed before the fetch may)
                 while (idle && ch_pend) {
                     const int j = __builtin_ctzll(ch_pend);
                     ch_pend &= ch_pend - 1ull;
                     const int gg = __builtin_ctzll(idle) >> 3;
                     idle &= idle - 1ull;
                     const int sxj = __builtin_amdgcn_readlane(ch_sx, j), syj = __builtin_amdgcn_readlane(ch_sy, j);
-                    if (grp == gg) { gk = ch_k0 + j; gwx = sxj - 7; gwy = syj - 7; ld = true; }
-                }
-                tw_small = true;
-                // the window: 16 rows of 16 packed pixel words around the seed; lane kq loads quarter kq & 3 of rows (kq >> 2) + 2 j
-                const int q4 = (kq & 3) * 4, r0 = kq >> 2;
-                const int x0 = gwx + q4;
-                uint32_t seedraw = 0u;
-                #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int row = r0 + 2 * j, y = gwy + row;
-                    uint32_t v0 = kPwStatic, v1 = kPwStatic, v2 = kPwStatic, v3 = kPwStatic;   // outside the image: banned
-                    if (ld && (unsigned)y < (unsigned)h) {
-                        const uint32_t* rowp = c.pw + (size_t)y * w;
-                        if (x0 >= 0 && x0 + 3 < w) {
-                            struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; };
-                            const Q4 qv = *reinterpret_cast<const Q4*>(rowp + x0);
-                            v0 = qv.a; v1 = qv.b; v2 = qv.c; v3 = qv.d;
-                        } else {
+                    if (grp == gg) { gk = ch_k0 + j; gld = true; gsnap = snap; }
+                    gldm |= 1ull << (8 * gg);
+                    // the window: 16 rows of 16 packed pixel words around the seed, as they are in pw[]; lane l fetches quarter l & 3 of row l >> 2
+                    const int wx = sxj - 7, wy = syj - 7;
+                    uint32_t* const win = G_ARENA(wave) + gg * 256;
+                    const int row = lane >> 2, q4 = (lane & 3) * 4;
+                    if (wx >= 0 && wx + 15 < w && wy >= 0 && wy + 15 < h) {
+                        // LDS-DMA: lane l's 16 bytes land at M0 + 16 l -- the window's layout
+                        const uint32_t* src = c.pw + (size_t)(wy + row) * w + (wx + q4);
+                        const uint32_t la = (uint32_t)uni((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)win);
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(la), "v"(src) : "memory", "m0");
+                    } else {
+                        const int y = wy + row, x0 = wx + q4;
+                        uint32_t v0 = kPwStatic, v1 = kPwStatic, v2 = kPwStatic, v3 = kPwStatic;   // outside the image: banned
+                        if ((unsigned)y < (unsigned)h) {
+                            const uint32_t* rowp = c.pw + (size_t)y * w;
                             if ((unsigned)(x0 + 0) < (unsigned)w) v0 = rowp[x0 + 0];
                             if ((unsigned)(x0 + 1) < (unsigned)w) v1 = rowp[x0 + 1];
                             if ((unsigned)(x0 + 2) < (unsigned)w) v2 = rowp[x0 + 2];
                             if ((unsigned)(x0 + 3) < (unsigned)w) v3 = rowp[x0 + 3];
                         }
-                    }
-                    if (j == 3) seedraw = v3;              // (row 7, column 7 of the window: lane kq == 5 holds the seed's own word)
-                    if (ld) {
-                        uint4 o;
-                        o.x = (v0 & ~3u) | (v0 & 1u); o.y = (v1 & ~3u) | (v1 & 1u); o.z = (v2 & ~3u) | (v2 & 1u); o.w = (v3 & ~3u) | (v3 & 1u);
-                        *reinterpret_cast<uint4*>(&swin[row * 16 + q4]) = o;
+                        *reinterpret_cast<uint4*>(&win[lane * 4]) = uint4{v0, v1, v2, v3};
                     }
                 }
-                // seeds used meanwhile (:222); the others start with their own pixel (:515-520)
-                const unsigned long long usedm = ballot64(ld && kq == 5 && (seedraw & 3u) != 0u);
-                const bool used = ((usedm >> (lane & 56)) & 0xffull) != 0ull;
-                const uint32_t sw = swin[7 * 16 + 7];
-                if (ld && !used) {
-                    float s0, c0;
-                    fast_sincos(__uint_as_float(sw & ~3u), s0, c0);
-                    gC = c0; gS = s0; gn = 1; gi = 0; gex = 1; gsnap = snap;
-                    if (kq == 0) { swin[7 * 16 + 7] = sw | 2u; slst[0] = (7u << 4) | 7u; }
-                }
-                if (ld && used) {
-                    if (kq == 0) st_st(&rg.state[gk & (RW - 1)], R_SKIP);
-                    gk = -1;
-                }
-                if (usedm) adv = true;
+                gld_age = 0;
                 progress = true;
                 DSTAT(ST_SLOW, 1);                          // (refill rounds)
                 LT(ST_TREFILL);
             }
         }
+        if (gldm && (ballot64(gk >= 0 && !gld) == 0ull || ++gld_age >= kWinAge)) window_arrived();
         if (ballot64(gk >= 0)) {
             // ---- one step: every active group tests the 8 neighbours of its next list entry ----
-            const bool act = gk >= 0;
+            const bool act = gk >= 0 && !gld;
             const uint32_t e = slst[act ? gi : 0];
             const int lx = (int)(e & 15u) + ox, ly = (int)(e >> 4) + oy;
             const bool inwin = ((unsigned)lx < 16u) & ((unsigned)ly < 16u);
@@ -2556,7 +2566,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             const uint32_t word = swin[cell];
             // a neighbour outside the window: the region is not small enough for this grower
             bool bail = ((ballot64(act & !inwin) >> (lane & 56)) & 0xffull) != 0ull;
-            bool todo = act & inwin & ((word & 3u) == 0u) & !bail;        // :536-537 (2 is growable, Q5)
+            bool todo = act & inwin & ((word & 1u) == 0u) & !bail;        // :536-537 (codes 0 and 2 are growable, Q5; a member gets bit 0)
             float sf, cf;
             fast_sincos(__uint_as_float(word & ~3u), sf, cf);
             while (ballot64(todo)) {
@@ -2577,7 +2587,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                 const float cl = sum8(kq == l ? cf : 0.0f);
                 const float sl = sum8(kq == l ? sf : 0.0f);
                 if (acc & (kq == l)) {
-                    swin[cell] = word | 2u;                                   // :549
+                    swin[cell] = word | 1u;                                   // :549
                     slst[gn] = (uint32_t)((ly << 4) | lx);                   // :551-556
                 }
                 gC += acc ? cl : 0.0f; gS += acc ? sl : 0.0f;                // :545-546 (estimate)
