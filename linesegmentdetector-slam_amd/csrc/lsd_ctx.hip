@@ -260,6 +260,7 @@ static int waves_for(const lsd_ctx* c, int n) {
 
 // Workgroups that own no image and help from the start (k_region.hip): as many as the images leave workgroup slots of the device
 // free -- one 8-wave workgroup per CU, three 4-wave ones -- and the images' helper wavefronts (tun_help each) can use.
+constexpr int kHelpDefaultImages = 64;  // calls with more images run without help across workgroups unless lsd_set_region_help asks for it
 constexpr int kPoolHelpMax = 64;        // helper wavefronts per image the pool is sized for at most (workspace: a wave slot each)
 static int pool_for(const lsd_ctx* c, int n, int help) {
     if (help < 0) help = 24;
@@ -558,7 +559,10 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 192 * nw;
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
-        b.tun_help = c->tun_help >= 0 ? c->tun_help : 24;
+        // help across workgroups by default only for calls of up to kHelpDefaultImages images: measured on the bench maps (round 5, one step at
+        // a time on 8 waves, profiles/r05y_onestep_n.log) 16 / 64 images: 39 / 51 ms with or without; 128 / 256 / 384 / 512 images:
+        // 56 / 61 / 71 / 83 ms with, 51 / 54 / 66 / 78 without -- every image of a large batch pays for the protocol and few are helped
+        b.tun_help = c->tun_help >= 0 ? c->tun_help : (n <= kHelpDefaultImages ? 24 : 0);
         b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_gate = c->tun_gate; b.tun_share = c->tun_share; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
         b.tun_xpoll = c->tun_xpoll; b.tun_linger = c->tun_linger; b.tun_stop = c->tun_stop;
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;
