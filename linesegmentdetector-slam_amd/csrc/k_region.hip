@@ -2783,6 +2783,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         adv = true;
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (an image given up by the watchdog may leave a window fetch in flight: nothing lands in LDS after the wave is gone)
     // ---- this image is finished (every seed committed, or given up): results out ----
     if (wave == 0 && lane == 0 && !pool) {
         b.counts[img] = lds_ld(&s_abort) ? -1 : s_lines;
