@@ -26,7 +26,7 @@ rows = [
         j["kernel_ms_in_timed_region"][x] for x in ("gauss", "gradient", "sort", "lines"))) if j.get("kernel_ms_in_timed_region") else ("front end in the timed region", "n/a"),
     ("`roofline` (K2)", "%.0f GB/s algorithmic = **%.3f** of 8 TB/s (launch %.3f ms); PMC traffic %s GB per launch; device copy in the same process %s GB/s" % (
         rf["achieved"], rf["frac"], rf["avg_launch_ms"], "%.2f" % (rf["traffic"] / 1e9) if rf.get("traffic") else "n/a", "%.0f" % rf["measured_copy_GBs"] if "measured_copy_GBs" in rf else "n/a")),
-    ("K4 cycles per image", "alone (8 waves, help on): mean %.1f M, max %.1f M; timed region (%s): mean %.1f M, max %.1f M" % (
+    ("K4 cycles per image", "alone (8 waves, the library's defaults): mean %.1f M, max %.1f M; timed region (%s): mean %.1f M, max %.1f M" % (
         dk["cycles_per_image"]["mean"] / 1e6, dk["cycles_per_image"]["max"] / 1e6, dk["timed_region"]["variant"], dk["timed_region"]["cycles_per_image"]["mean"] / 1e6, dk["timed_region"]["cycles_per_image"]["max"] / 1e6)),
     ("whole step vs HBM", "%.1f GB algorithmic per step -> %.0f GB/s = %.3f of peak (`roofline_pipeline`)" % (j["roofline_pipeline"]["algorithmic_bytes_per_step"] / 1e9, j["roofline_pipeline"]["achieved"], j["roofline_pipeline"]["frac"])),
 ]
