@@ -1818,6 +1818,7 @@ __device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
 __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATTR void k_region(Geom g, Buffers b, uint32_t id_base) {
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort, s_nsets;
+    __shared__ int s_scan[NW];                              // the waves' counts of potential seeds (the seed scan at the start)
     __shared__ short s_ring[RING][4];
     __shared__ Ring rg;
     __shared__ SlotTab stab;
@@ -1883,23 +1884,51 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         sincos_g(g.degThre < 1.5 ? g.degThre : 1.0, st, ct);
         if (lane == 0) { g_tol0[0] = g.degThre; g_tol0[1] = st; g_tol0[2] = ct; }
     }
-    // potential seeds: sorted entries whose pixel is not below the gradient threshold (usedMap == 0 after K2)
-    if (wave == 0) {
-        int cnt = 0;
+    // potential seeds: sorted entries whose pixel is not below the gradient threshold (usedMap == 0 after K2), in sorted order.  Every
+    // wave takes a contiguous share of the list, four chunks of 64 entries per trip to memory (an entry costs two dependent reads:
+    // its position, then that pixel's word): first the counts, then -- the shares' offsets known -- the same walk again, writing
+    // (one wave walking the whole list chunk by chunk took ~0.8 ms of a 2048 x 2048 map's 9).
+    {
+        const int nchunks = (nb + 63) >> 6, per = (nchunks + NW - 1) / NW;
+        const int c0 = min(wave * per, nchunks), c1 = min(c0 + per, nchunks);
         const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int base = 0; base < nb; base += 64) {
-            const int idx = base + lane;
-            const uint32_t pq = ord[idx < nb ? idx : 0];
-            const bool ok = idx < nb && (c.pw[pq] & 3u) == 0u;   // :222
-            const unsigned long long m = ballot64(ok);
-            if (ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)idx; seedpos[o] = pq; }
-            cnt += __builtin_popcountll(m);
+        int cnt = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int ch = c0; ch < c1; ch += 4) {
+                uint32_t pq[4], cw[4];
+                bool in[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx = (ch + u) * 64 + lane;
+                    in[u] = ch + u < c1 && idx < nb;
+                    pq[u] = ord[in[u] ? idx : 0];
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) cw[u] = c.pw[pq[u]];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool ok = in[u] && (cw[u] & 3u) == 0u;                   // :222
+                    const unsigned long long m = ballot64(ok);
+                    if (pass == 1 && ok) { const int o = cnt + __builtin_popcountll(m & lt); seedidx[o] = (uint32_t)((ch + u) * 64 + lane); seedpos[o] = pq[u]; }
+                    cnt += __builtin_popcountll(m);
+                }
+            }
+            if (pass == 0) {
+                if (lane == 0) s_scan[wave] = cnt;
+                __syncthreads();
+                int off = 0, tot = 0;
+                for (int v = 0; v < NW; v++) { const int t = s_scan[v]; off += v < wave ? t : 0; tot += t; }
+                cnt = off;
+                if (wave == 0 && lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(tot, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nsets = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
+            }
         }
-        if (lane == 0) { s_next = 0; s_commit = 0; s_epoch = 0; s_lines = 0; s_ntrace = 0; s_nseeds = seed_limit(cnt, b.tun_stop); s_lock = 0; s_nbig = 0; s_depth = min(max(b.tun_soft, 2 * CH), RW - 128); s_abort = 0; s_nsets = 0; s_nhelp = 0; s_xout = 0; s_xlock = 0; s_xreg = 0; s_xpub = 0; s_idlecnt = 0; s_xc_last = 0; s_xt_last = (int)__builtin_amdgcn_s_memtime(); s_workbound = 0; }
         wg_fence();
-        if (xr) agent_release();                           // helpers on other XCDs read seedpos[] as soon as a request names a seed
+        __syncthreads();
+        if (xr) {                                           // helpers on other XCDs read seedpos[] as soon as a request names a seed
+            if (wave == 0) agent_release();
+            __syncthreads();
+        }
     }
-    __syncthreads();
     const int nseeds = s_nseeds;
 
     // How far the hand-out and the full evaluations may run ahead of the cursor (s_depth, in seeds).  The further ahead a region is
@@ -2368,7 +2397,7 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     uint32_t* const swin = G_ARENA(wave) + grp * 256;       // this group's window (the arena holds no full evaluation meanwhile)
     uint32_t* const slst = G_ARENA(wave) + 8 * 256 + grp * SCAP;   // this group's list: ly << 4 | lx
     int gk = -1;                                            // seed of this lane's group, -1: idle
-    int gn = 0, gi = 0, gex = 0, gwx = 0, gwy = 0, gsnap = 0;
+    int gn = 0, gi = 0, gex = 0, gsnap = 0;
     float gC = 0.0f, gS = 0.0f;                             // estimated sum vector of the group's region
     int ch_k0 = 0, ch_sx = 0, ch_sy = 0;                    // the wave's chunk: lane j < CH holds seed ch_k0 + j
     unsigned long long ch_pend = 0ull;                      // seeds of the chunk not handed to a group yet
@@ -2535,7 +2564,11 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
                         // LDS-DMA: lane l's 16 bytes land at M0 + 16 l -- the window's layout
                         const uint32_t* src = c.pw + (size_t)(wy + row) * w + (wx + q4);
                         const uint32_t la = (uint32_t)uni((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)win);
+                        // (M0 is the compiler's to manage and it says so; nothing else in this kernel uses it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
                         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(la), "v"(src) : "memory", "m0");
+#pragma clang diagnostic pop
                     } else {
                         const int y = wy + row, x0 = wx + q4;
                         uint32_t v0 = kPwStatic, v1 = kPwStatic, v2 = kPwStatic, v3 = kPwStatic;   // outside the image: banned
