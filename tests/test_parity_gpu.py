@@ -1133,6 +1133,29 @@ def test_help_across_workgroups_changes_nothing(waves, maps, lsdmod, oracle):
     assert res["24"][3] > 20 and res["24"][4] > 20, res["24"][3:]      # (hundreds on an idle device)
 
 
+def test_large_batches_run_without_help_by_default(maps, lsdmod, oracle):
+    """Help across workgroups is the default for calls of up to 64 images only (lsd_ctx.hip: kHelpDefaultImages): in a larger batch
+    no image exports a seed unless lsd_set_region_help asks for it -- and asking changes no byte of the result."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    heavy = bench.make_image(maps, 27, 2048)[:1024, :1024]
+    light = bench.make_image(maps, 0, 2048)[:1024, :1024]
+    batch = np.ascontiguousarray(np.stack([heavy] + [light] * 65))
+    wh = lsdmod.scaled_size(1024, 1024)
+    res = {}
+    for help_ in (-1, 24):
+        c = lsdmod.Context(0)
+        c.set_region_waves(8); c.set_region_help(help_)
+        lines, offs, ims = c.run_batch(batch.copy())
+        res[help_] = (lines.tobytes(), offs.tobytes(), ims.tobytes(), sum(c.fetch(i, lsdmod.DBG_STATS, wh)["help_exports"] for i in range(len(batch))))
+        c.close()
+    assert res[-1][3] == 0, res[-1][3]
+    assert res[-1][:3] == res[24][:3]
+    ref = oracle.lsd(batch[0].copy())
+    n0 = np.frombuffer(res[-1][1], np.int32 if len(res[-1][1]) == 4 * (len(batch) + 1) else np.int64)
+    assert n0[1] - n0[0] == len(ref["lines"])
+
+
 @pytest.mark.parametrize("tun", [{"REQUEUE": 0}, {"SOFT": 64, "CLAIM": 64}, {"SOFT": 1900, "CLAIM": 1900, "BIG": 16},
                                  {"HELP": 64, "WB": 100, "XPOLL": 2000}])
 def test_schedule_of_the_region_stage_changes_nothing(tun, maps, lsdmod, ctx):
