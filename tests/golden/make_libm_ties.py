@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/libm_ties.npz: the images of the random parity campaigns (tools/campaign.py, 60 000 images + 1 800 large ones,
-profiles/r04u_campaign_*.log) on which the HIP path and the glibc-built oracle disagree by one accept / reject decision.  On every
+"""Writes tests/golden/libm_ties.npz: the images of the random parity campaigns (tools/campaign.py, 90 000 images + 2 400 large ones,
+profiles/r04u_campaign_*.log, profiles/r05h_campaign_*.log) on which the HIP path and the glibc-built oracle disagree by one accept / reject decision.  On every
 one of them glibc misrounds a sin / cos / atan2 by one ulp on a structural tie (a rectangle edge exactly on a pixel row); the HIP
 path evaluates those functions correctly rounded and equals the restatement rebuilt on correctly rounded functions
 (oracle/liblsd_oracle_cr.so) bit for bit.  The images are pure functions of their campaign number (tools/campaign_images.py).
@@ -18,12 +18,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from campaign_images import campaign_image  # noqa: E402
 from oracle import oracle  # noqa: E402
 
-SMALL = [2995, 1759, 6382, 10647, 18262, 27264, 38359, 40212, 45813, 48150, 54902, 55115, 56831, 58631]
+SMALL = [2995, 1759, 6382, 10647, 18262, 27264, 38359, 40212, 45813, 48150, 54902, 55115, 56831, 58631,
+         68894, 73163, 75918, 79924, 80225, 80295, 83780]      # (the second row: images 60 000 .. 89 999, profiles/r05h_campaign_fresh30000.log)
 BIG = [297]
-# ... and the one image of the campaigns with an NFA comparison inside what an ulp of exp / log10 / pow can move (margin 0.27: two hopeless
+# ... and the images of the campaigns with an NFA comparison inside, or within a factor two of, what an ulp of exp / log10 / pow can move (705: margin 0.27: two hopeless
 # rectangles, 5 aligned pixels of 656, whose tails are 1 - 1e-15, so that logNFA = -logNT to the last place): both builds decide alike on
 # it -- kept so that a libm (or a change of the device routines) that decides otherwise shows up
-NEAR = [705]
+NEAR = [705, 1854, 2331]                                  # (1854, 2331: margins 1.3 and 1.5, profiles/r05h_campaign_big_fresh600.log)
 NAMES = {2995: "tie_a", 1759: "tie_b"}                     # (the two fixtures of round 3 keep their names)
 
 out, table = {}, {}

@@ -246,8 +246,9 @@ LIBM_TIES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "li
 
 @pytest.mark.parametrize("name", sorted(LIBM_TIES))
 def test_libm_tie_images_document_the_one_caveat(name, oracle):
-    """tests/golden/libm_ties.npz (written by make_libm_ties.py): ALL 15 images of the random campaigns (60 000 + 1 800 large ones,
-    tools/campaign.py) on which the HIP path and the glibc-built restatement disagree.  The restatement rebuilt on correctly rounded
+    """tests/golden/libm_ties.npz (written by make_libm_ties.py): ALL 22 images of the random campaigns (90 000 + 2 400 large ones,
+    tools/campaign.py) on which the HIP path and the glibc-built restatement disagree, and the three with an NFA comparison below the
+    campaign's margin floor (`near*`).  The restatement rebuilt on correctly rounded
     functions (oracle/cr_shim.cpp) differs from the glibc one in exactly the recorded way: one accept / reject decision on a
     structural tie that a 1-ulp libm difference turns; the same seeds, the same regions up to there."""
     img = np.load(os.path.join(os.path.dirname(__file__), "golden", "libm_ties.npz"))[name]
@@ -259,8 +260,9 @@ def test_libm_tie_images_document_the_one_caveat(name, oracle):
     assert len(a["lines"]) == t["lines_glibc"], "this libm rounds differently from the glibc the campaign ran against"
     assert int((a["dbg"]["used"] != b["dbg"]["used"]).sum()) == t["used_diff"]
     assert int((a["lineIm"] != b["lineIm"]).sum()) == t["lineim_diff"]
-    if name.startswith("near"):                                       # (an NFA comparison inside the libms' noise: the two builds decide alike on it)
-        assert t["used_diff"] == 0 and t["lineim_diff"] == 0 and a["dbg"]["nfa_min_gap"] < 1.0
+    if name.startswith("near"):                                       # (an NFA comparison inside the libms' noise, or within a factor two of it -- below the
+        #                                                                # floor tools/campaign.py enforces: the two builds decide alike on it)
+        assert t["used_diff"] == 0 and t["lineim_diff"] == 0 and a["dbg"]["nfa_min_gap"] < 2.0
         return
     assert t["used_diff"] + t["lineim_diff"] > 0
     sa, sb = a["dbg"]["seeds"], b["dbg"]["seeds"]

@@ -29,7 +29,8 @@ CR_EVERY = int(os.environ.get("CAMPAIGN_CR", "10"))          # every n-th image 
 bad = cr_bad = cr_n = 0
 nfa_abs, nfa_gap = float('inf'), float('inf')      # smallest margins of the campaign's NFA comparisons
 t0 = time.time()
-for i in (only or range(n_img)):
+first = int(os.environ.get("CAMPAIGN_FIRST", "0"))           # image numbers first .. first + n - 1 (fresh images: past what earlier campaigns saw)
+for i in (only or range(first, first + n_img)):
     img, kw, waves = campaign_image(i, BIG)
     ctx.set_region_waves(waves)
     ref = oracle.lsd(img.copy(), debug=True, **kw)
