@@ -65,6 +65,23 @@ def make_image(maps, i, size):
     return np.ascontiguousarray(canvas)
 
 
+REAL_MAPS = ["map1", "mapValue", "aisle1", "aisle2", "aisle3", "f3key", "f4key"]   # the reference's own maps, un-tiled (data*/mapValue*.txt)
+
+
+def make_pasted(maps, size=2048):
+    """One size x size canvas of DIFFERENT reference maps side by side on the maps' own background value (0: every fixture's border is
+    0), nothing tiled, rolled or wrapped -- so no seams and no repeated structure: f3key top left, f4key below it, aisle3 turned by 90
+    degrees along the right edge.  Only defined for size >= 2048."""
+    if size < 2048:
+        return None
+    c = np.zeros((size, size), np.uint8)
+    a, b, r = maps["f3key"], maps["f4key"], np.ascontiguousarray(np.rot90(maps["aisle3"]))
+    c[:a.shape[0], :a.shape[1]] = a
+    c[990:990 + b.shape[0], :b.shape[1]] = b
+    c[:r.shape[0], size - r.shape[1]:] = r
+    return c
+
+
 def make_batch(maps, n, size, first=0):
     out = np.empty((n, size, size), np.uint8)
     for j in range(n):
@@ -170,6 +187,19 @@ def cpu_baseline(size, first, sample=24, reps=5):
         oracle.lsd(m, want_lineim=True)
         t0s.append(time.perf_counter() - t0)
     out["single_image_ms"] = min(t0s[1:]) * 1e3
+    # the port on the reference's own maps as they are, and on the pasted canvas (what extras() times on the GPU as `real_maps`)
+    rm = {}
+    mp_ = load_maps()
+    todo = [(k, mp_[k]) for k in REAL_MAPS] + ([("pasted2048", make_pasted(mp_, size))] if size >= 2048 else [])
+    for name, im in todo:
+        ts_ = []
+        for _ in range(3):
+            m = im.copy()
+            t0 = time.perf_counter()
+            r = oracle.lsd(m, want_lineim=True)
+            ts_.append(time.perf_counter() - t0)
+        rm[name] = {"ms": min(ts_[1:]) * 1e3, "lines": len(r["lines"])}
+    out["real_maps"] = rm
     unpin()
     try:                                                            # N-core figure: N independent pinned instances over disjoint images
         import multiprocessing as mp
@@ -213,6 +243,58 @@ def cpu_baseline(size, first, sample=24, reps=5):
     return out
 
 
+def launch_command(argv, gpus, port=None):
+    """The command line that starts one rank per GPU (what the driver's own launch looks like): used when bench.py is started with
+    --gpus N > 1 and no rendezvous in the environment.  `argv` = this process's arguments without the launcher-only flags."""
+    if port is None:
+        import socket
+        with socket.socket() as s_:                                 # a free port on the loopback interface (the container's hostname may not resolve)
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(a, argv):
+    """`python3 bench.py --gpus N` without an external torch.distributed.run: start the N ranks as a CHILD job, relay its output (the one
+    JSON line of rank 0) and return its exit code.  Nothing in this process has touched the GPU (torch is not even imported yet) --
+    replacing a process that has initialised HIP by another program takes the box down on this pool, so the ranks are children, never
+    an exec.  --dry-launch prints the command instead of running it (tests/test_bench_host.py)."""
+    import subprocess
+    argv = [x for x in argv if x != "--dry-launch"]
+    n_vis = None
+    try:
+        import torch                                                # device_count() alone does not initialise the GPU on this image
+        n_vis = torch.cuda.device_count()
+    except Exception:
+        pass
+    cmd = launch_command(argv, a.gpus)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # RCCL / dmabuf IPC on this pool (the image exports it already)
+    env.setdefault("GPU_MAX_HW_QUEUES", "16")
+    if a.dry_launch:
+        print(json.dumps({"launch": cmd, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES")}, "visible_gpus": n_vis}), flush=True)
+        return 0
+    if n_vis is not None and n_vis < a.gpus:
+        print("bench.py: --gpus %d but this node shows %d GPU(s)" % (a.gpus, n_vis), file=sys.stderr)
+        return 2
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def fit_depth(depth, need_per_slot, need_fixed, free_bytes, floor=4):
+    """Steps in flight that fit the free HBM of this rank: `depth` if depth x need_per_slot + need_fixed fits, else the largest depth
+    >= 1 that does (never above `depth`).  Returns (depth, note or None).  DESIGN.md section 5: 4 in flight cost ~3 % against 8."""
+    if depth <= 1 or depth * need_per_slot + need_fixed <= free_bytes:
+        return depth, None
+    fit = int((free_bytes - need_fixed) // max(1, need_per_slot))
+    new = max(1, min(depth, fit))
+    if new >= floor:
+        new = max(floor, new)
+    return new, ("%d steps in flight need %.0f GB of HBM (%.1f GB per slot), %.0f GB are free on this GPU: running %d in flight"
+                 % (depth, (depth * need_per_slot + need_fixed) / 1e9, need_per_slot / 1e9, free_bytes / 1e9, new))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,7 +317,13 @@ def main():
     ap.add_argument("--cost-history", action="store_true", help="experiments: lsd_set_cost_history(1) on every context of the timed region")
     ap.add_argument("--tail-help", type=int, default=0, help="experiments: the last N steps of the timed region are enqueued with the help across workgroups ON (no further "
                     "step will come to fill the CUs their last images leave idle); measured with 20 steps at depth 8: 0 / 4 / 7 / 8 -> 44.9 / 45.3 / 46.8 / 68.4 ms per step")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the command that would start the ranks and exit")
     a = ap.parse_args()
+
+    # `python3 bench.py --gpus N` started the way `--gpus 1` is (no torch.distributed.run around it): start the ranks ourselves, as a
+    # child job, BEFORE anything here touches the GPU
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -273,6 +361,20 @@ def main():
     # CUs a step's last images leave idle, helpers would hold them (include/lsd_hip.h, lsd_set_region_help).
     depth = max(1, a.pipeline)
     waves = a.waves if a.waves >= 0 else (4 if depth > 1 else 0)
+    # Does the depth fit this GPU?  A slot = one context's workspace (lsd_reserve: 103 B per scaled pixel on 4 wavefronts per image, 146 on
+    # 8; include/lsd_hip.h) + its output buffers: ~22 GB for 512 x 2048^2 maps, ~180 GB at depth 8 of the 288 GB.  A GPU that does not
+    # have that free (another tenant, a smaller part) runs fewer steps in flight -- 4 cost ~3 % -- and says so.
+    ws_w, ws_h = lsd.scaled_size(size, size)
+    slot_bytes = int(n * ((103 if waves == 4 else 146) * ws_w * ws_h * 1.03 + a.max_lines * 80 + 4 + (0 if a.no_lineim else size * size)))
+    depth_asked = depth
+    depth, depth_note = fit_depth(depth, slot_bytes, 2 << 30, torch.cuda.mem_get_info(dev)[0])
+    if depth_note and rank == 0:
+        print("bench.py: " + depth_note, file=sys.stderr)
+    if use_dist:                                            # every rank the same depth (the gathers are issued per slot, in the same order everywhere)
+        dmin = torch.tensor([depth], dtype=torch.int32, device=dev)
+        dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+        depth = int(dmin.item())
+    waves = a.waves if a.waves >= 0 else (4 if depth > 1 else 0)
     ctxs = [ctx] + [lsd.Context(local) for _ in range(depth - 1)]
     outs = [(torch.zeros((n, a.max_lines, 10), dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
              None if a.no_lineim else torch.zeros((n, size, size), dtype=torch.uint8, device=dev)) for _ in range(depth)]
@@ -297,17 +399,22 @@ def main():
 
     tail_help = max(0, a.tail_help) if depth > 1 else 0
 
+    # what a step works on: this rank's images of the job (the weak job by default; the strong split of the same batch re-uses the
+    # contexts and output buffers for its smaller shard, see "strong_split" below)
+    job = {"maps": d_maps, "n": n, "n_total": n_total, "cap_rows": cap_rows}
+
     def step(i, collect, last=False):
         j = i % depth
         l_, c_, im_ = outs[j]
+        m_ = job["n"]
         if depth > 1:                                      # (a host-side setting of the context, read at the enqueue)
             ctxs[j].set_region_help(-1 if last else a.help_waves)
-        ctxs[j].enqueue_device(d_maps.data_ptr(), n, size, size, l_.data_ptr(), a.max_lines, c_.data_ptr(),
+        ctxs[j].enqueue_device(job["maps"].data_ptr(), m_, size, size, l_.data_ptr(), a.max_lines, c_.data_ptr(),
                                d_line_ims=None if im_ is None else im_.data_ptr(), stream=tstreams[j].cuda_stream)
         res = None
         if use_dist:
             with torch.cuda.stream(tstreams[j]):
-                res = ldist.gather_lines_abi(ctxs[j], comm, l_, c_, n_total, cap_rows, stream=tstreams[j].cuda_stream)
+                res = ldist.gather_lines_abi(ctxs[j], comm, l_[:m_], c_[:m_], job["n_total"], job["cap_rows"], stream=tstreams[j].cuda_stream)
         if collect:                                        # HIP events recorded on the launch stream by the library (this waits for the step)
             for k, v in ctxs[j].timings().items():
                 kt[k] += v
@@ -336,6 +443,38 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    # The strong split next to the weak line (N > 1, --scaling weak): the SAME --batch images (rank 0's) split over the ranks in contiguous
+    # shards (BASELINE configs[4], the split north_star's "1 -> 8 GPUs on a 512-image batch" means), same contexts, same depth, same
+    # protocol (barrier, K steps, barrier, max over ranks).  A shard is 1/N of the images, so a rank's GPU is 1/N as full as in the weak
+    # job: DESIGN.md section 6 says what that costs and what a rank that keeps N x as many steps in flight gets back.
+    strong_dt = None
+    if world > 1 and a.scaling == "weak":
+        lo_s, hi_s = ldist.shard_range(a.batch, world, rank)
+        strong_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        try:
+            d_shard = torch.from_numpy(make_batch(maps, hi_s - lo_s, size, lo_s)).to(dev)
+        except Exception as e:                             # (this rank cannot take part: every rank skips the pass, see below)
+            print("bench.py rank %d: strong split skipped: %r" % (rank, e), file=sys.stderr)
+            d_shard = None
+            strong_err += 1
+        dist.all_reduce(strong_err, op=dist.ReduceOp.MAX)
+        if int(strong_err.item()) == 0:
+            job_weak = dict(job)
+            job.update({"maps": d_shard, "n": hi_s - lo_s, "n_total": a.batch, "cap_rows": max(hi_s - lo_s, 1) * 512})
+            for i in range(min(a.warmup, depth)):
+                step(i, False)
+            barrier()
+            t0s = time.perf_counter()
+            for i in range(a.steps):
+                step(i, False)
+            torch.cuda.synchronize()
+            barrier()
+            strong_dt = time.perf_counter() - t0s
+            job.update(job_weak)
+            for i in range(depth):                         # the slots' outputs and gathered copies hold the weak job's step again (read and checked below)
+                res_slot[i] = step(i, False)
+            barrier()
+        del d_shard
     # the front end inside the timed region: HIP events of every slot's LAST step, event to event -- with several steps in flight that
     # includes the wait for room beside the region stage's workgroups (one step at a time: kernel_ms below)
     tr_front = [c_.timings() for c_ in ctxs[:min(depth, a.steps)]] if depth > 1 else []
@@ -371,12 +510,13 @@ def main():
         hist_dt = time.perf_counter() - t2
         ctx.set_cost_history(False)
         depth = depth_saved
-    tmax = torch.tensor([dt, un_dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, un_dt, strong_dt or 0.0], dtype=torch.float64, device=dev)
     nl = last[1].sum().to(torch.float64).reshape(1)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nl, op=dist.ReduceOp.SUM)
     dt, un_dt = float(tmax[0].item()), float(tmax[1].item())
+    strong_dt = float(tmax[2].item()) if strong_dt else None
     total_lines = float(nl.item())
     overflow = int((last[1] > a.max_lines).sum().item())
 
@@ -422,7 +562,8 @@ def main():
                        "images_total": n_total, "images_rank0": n, "image": [size, size], "scaled": [w, h],
                        "parallelism": "image-sharded x%d, RCCL gather of line lists" % world if world > 1 else "single GPU",
                        "rccl_gather_in_step": bool(use_dist),
-                       "steps_in_flight": depth, "region_waves_per_image": waves if waves else 8,
+                       "steps_in_flight": depth, "steps_in_flight_asked": depth_asked, "steps_in_flight_note": depth_note,
+                       "hbm_bytes_per_slot": slot_bytes, "region_waves_per_image": waves if waves else 8,
                        "help_across_workgroups": bool(depth == 1 or a.help_waves),
                        # the last steps of the timed region run with the help ON: nothing follows them that could fill the idle CUs
                        "last_steps_with_help": tail_help,
@@ -438,6 +579,12 @@ def main():
                                                      "note": "lsd_set_cost_history(1): the same batch again, its images started in the order of their cost in the previous "
                                                              "step (a caller re-extracting one site's maps); rank 0's clock, not part of `value`"} if hist_dt else None),
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
+            # N > 1 only: the same --batch images split over the ranks (the strong split), timed like the weak job right after it
+            "strong_split": ({"scaling": "strong", "images_total": a.batch, "ms_per_step": strong_dt / a.steps * 1e3,
+                              "value": a.batch * size * size / 1e6 / (strong_dt / a.steps), "unit": "Mpix/s", "steps": a.steps,
+                              "steps_in_flight": depth,
+                              "note": "rank 0's %d images in contiguous shards over the %d ranks, RCCL gather of the line lists in every step; same contexts and "
+                                      "depth as the weak job, max over ranks; compare with the N = 1 line's value" % (a.batch, world)} if strong_dt else None),
             "kernel_ms": {k: v / un_steps for k, v in kt.items()},
             # the same kernels inside the timed region, event to event (mean over the slots' last steps): what the front end of a step
             # takes while the region stages of the other steps in flight hold the CUs
@@ -481,6 +628,11 @@ def main():
             m1["single_call_vs_port"] = cb["map1"]["ms"] / m1["single_call_lsd_only_ms"]
             out["single_image_latency_vs_port"] = cb["single_image_ms"] / out["single_image_latency_ms"]
             out["vs_port_one_core"] = out["value"] / cb["value"]
+            for name, rec in out.get("real_maps", {}).items():
+                if name in cb.get("real_maps", {}):
+                    rec["port_ms_per_map"] = cb["real_maps"][name]["ms"]
+                    rec["port_lines"] = cb["real_maps"][name]["lines"]
+                    rec["vs_port_one_core"] = cb["real_maps"][name]["ms"] * rec["copies"] / rec["ms"]
             if "value" in cb.get("all_cores", {}):
                 out["vs_port_all_cores"] = out["value"] / cb["all_cores"]["value"]
         print(json.dumps(out), flush=True)
@@ -543,6 +695,40 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
                            "the reference cannot be built on the GPU box; same-box ratios against the port: vs_port_one_core / vs_port_all_cores",
         "kernel_ms_batch512": ctx.timings()}
     del d1, l1, c1, i1
+    # -- the reference's own maps, un-tiled (LSD/main_on_windows.cpp:20-46 loads one of these per run): each replicated to a batch of
+    #    512 resident in HBM and run through the device entry point with the library's defaults, + one 2048^2 canvas of different
+    #    maps pasted side by side (no wrap-around seams, no repeated structure).  set_answers = evaluations the certified uniform
+    #    sets answered: how much of that mechanism survives outside the tiled bench batch.
+    real = {}
+    pasted = make_pasted(maps, size)
+    for name in REAL_MAPS + (["pasted2048"] if pasted is not None else []):
+        im = pasted if name == "pasted2048" else maps[name]
+        rr, cc = im.shape
+        dm = torch.from_numpy(np.broadcast_to(im, (reps, rr, cc)).copy()).to(dev)
+        ll = torch.zeros((reps, a.max_lines, 10), dtype=torch.int64, device=dev)
+        cn = torch.zeros(reps, dtype=torch.int32, device=dev)
+        li = torch.zeros((reps, rr, cc), dtype=torch.uint8, device=dev)
+        tt = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.enqueue_device(dm.data_ptr(), reps, cc, rr, ll.data_ptr(), a.max_lines, cn.data_ptr(), d_line_ims=li.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            if it:
+                tt.append(time.perf_counter() - t1)
+        assert int(cn.min().item()) == int(cn.max().item()) >= 0, name
+        tb_ = min(tt)
+        ws_, hs_ = lsd.scaled_size(cc, rr)
+        st_ = ctx.fetch(0, lsd.DBG_STATS, (ws_, hs_))
+        real[name] = {"image": [cc, rr], "copies": reps, "ms": tb_ * 1e3, "Mpix_per_s": reps * rr * cc / 1e6 / tb_, "lines": int(cn[0].item()),
+                      "lines_per_s": reps * int(cn[0].item()) / tb_, "lit_pixels": int((li[0] != 0).sum().item()), "kernel_ms": ctx.timings(),
+                      "grow_calls": st_["grow_calls"], "grown_px": st_["grown_px"], "set_answers": st_["set_answers"], "sets_founded": st_["sets_founded"],
+                      "region_Mcycles": st_["cycles_total"] / 1e6}
+        del dm, ll, cn, li
+    out["real_maps"] = real
+    out["real_maps_note"] = ("the reference's seven maps as they are (no tiling) and one 2048^2 canvas of three different maps pasted side by side, %d copies "
+                             "each, resident, library defaults, best of 3; vs_port_one_core (added next to cpu_baseline) = the port's time for the "
+                             "same number of maps on one core of this box / ms" % reps)
     # -- strong scaling projected from ONE GPU (BASELINE configs[4]: the same batch split over 2 / 4 / 8 GPUs, contiguous shards):
     #    every shard is run alone on this GPU; a step of the sharded job cannot be shorter than its slowest shard (+ the gather, 22 MB)
     if a.scaling == "weak" and n_total >= 8:

@@ -108,7 +108,9 @@ int lsd_enqueue_batch_device(lsd_ctx *ctx, uint8_t *d_maps, int n, int cols, int
 /* Pre-sizes the workspace so that lsd_enqueue_batch_device never allocates: 103 B per scaled pixel on 4 wavefronts per image, 146 B on
  * 8 (lsd_set_region_waves, below; call it first), i.e. 39 / 55 MB per 2048 x 2048 map at sca 0.3 -- 20.0 / 28.2 GB for 512 of them
  * (tools/workspace_size.py).  The workspace is sized for the helper pool of the default help setting even while help is off, so that
- * lsd_set_region_help never makes a later enqueue allocate. */
+ * lsd_set_region_help never makes a later enqueue allocate.  The lookup tables are sized here as well (log-gamma of every pixel count of
+ * this geometry, the Gaussian taps of the DEFAULT parameters): an enqueue of a larger geometry than any reserved one still grows them
+ * (one synchronisation, one allocation), an enqueue with other parameters rewrites the small ones (blocking copies, no allocation). */
 int lsd_reserve(lsd_ctx *ctx, int n, int cols, int rows);
 /* Blocks until the stream used by the last enqueue is idle. */
 int lsd_synchronize(lsd_ctx *ctx);
@@ -125,7 +127,8 @@ void lsd_shard_range(int n_items, int world, int rank, int *lo, int *hi);
  * cost about the same from step to step.  The gathered lists then arrive in perm order: image perm[g] at position g. */
 int lsd_shard_balanced(const long long *costs, int n_items, int world, int *perm);
 /* Shader clocks the region stage spent on each of the first n images of the context's last batch (synchronises): the cost
- * lsd_shard_balanced deals by.  An image the region stage gave up reports 0. */
+ * lsd_shard_balanced deals by.  An image the region stage gave up reports 0.  LSD_ERR_INVALID if the context's last call did not run
+ * the region stage on at least n images (lsd_set_stop_after). */
 int lsd_last_region_cycles(lsd_ctx *ctx, int n, long long *cycles_out);
 
 /* A communicator as this library sees it: who am I, how many are we, and ONE operation -- an all-gather of equally sized device

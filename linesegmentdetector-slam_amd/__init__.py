@@ -142,12 +142,12 @@ def load_library(path=None):
     if hasattr(L, "lsd_gather_lines") or not os.environ.get("LSD_HIP_LIB"):
         L.lsd_shard_range.restype = None; L.lsd_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         L.lsd_gather_layout.restype = i; L.lsd_gather_layout.argtypes = [i, i, C.POINTER(i), C.POINTER(sz)]
-    if hasattr(L, "lsd_shard_balanced") or not os.environ.get("LSD_HIP_LIB"):
-        L.lsd_shard_balanced.restype = i; L.lsd_shard_balanced.argtypes = [vp, i, i, vp]
-        L.lsd_last_region_cycles.restype = i; L.lsd_last_region_cycles.argtypes = [vp, i, vp]
         L.lsd_comm_from_rccl.restype = i; L.lsd_comm_from_rccl.argtypes = [vp, C.POINTER(lsd_comm)]
         L.lsd_gather_lines.restype = i; L.lsd_gather_lines.argtypes = [vp, C.POINTER(lsd_comm), vp, vp, i, i, i, i, vp, vp, vp]
         L.lsd_gather_unpack.restype = i; L.lsd_gather_unpack.argtypes = [vp, vp, i, i, i, vp, vp, sz]
+    if hasattr(L, "lsd_shard_balanced") or not os.environ.get("LSD_HIP_LIB"):      # (an A/B build with the gather entry points may predate these two)
+        L.lsd_shard_balanced.restype = i; L.lsd_shard_balanced.argtypes = [vp, i, i, vp]
+        L.lsd_last_region_cycles.restype = i; L.lsd_last_region_cycles.argtypes = [vp, i, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:

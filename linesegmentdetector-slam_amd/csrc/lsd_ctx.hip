@@ -435,12 +435,18 @@ int lsd_create(lsd_ctx** out, int device) {
     // -- LSD_REGION_<NAME> from the environment.  None changes a result (tests/test_parity_gpu.py::
     // test_schedule_of_the_region_stage_changes_nothing); every value is clamped to the range the kernel assumes.
     for (const Tuning& t : kTunings) {
-#ifndef LSD_DEVELOPER_KNOBS
-        if (!t.shipped) continue;
-#endif
         const std::string name = std::string("LSD_REGION_") + t.name;
         const char* e = getenv(name.c_str());
         if (!e || !*e) continue;
+#ifndef LSD_DEVELOPER_KNOBS
+        if (!t.shipped) {                               // say so once: a sweep script that drives the shipped library by these would measure one configuration n times
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "liblsdhip: %s is set but only read by the developer builds (make stats / exp, LSD_HIP_LIB=...); "
+                                         "use lsd_debug_set_tuning() with the shipped library\n", name.c_str());
+            warned = true;
+            continue;
+        }
+#endif
         char* end = nullptr;
         const long v = strtol(e, &end, 10);
         if (end == e) continue;
@@ -524,7 +530,13 @@ int lsd_reserve(lsd_ctx* c, int n, int cols, int rows) {
     int st = make_geom(&p, cols, rows, &g);
     if (st != LSD_OK) return st;
     HIPCHK(c, hipSetDevice(c->device));
-    return ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)g.gp * g.h, c->cap_max_lines, c->trace);
+    st = ensure_workspace(c, (size_t)n, (size_t)g.npx, (size_t)g.gp * g.h, c->cap_max_lines, c->trace);
+    if (st != LSD_OK) return st;
+    // ... and the tables: the log-gamma table is sized by the geometry (w*h + 2 host-libm values: ~40 ms of host work and a blocking
+    // copy for a 2048^2 map), taps / centres / log p for the default parameters.  Done here, the first enqueue after a reserve neither
+    // allocates nor synchronises; ensure_tables' own grow path stays as the fallback for a LARGER geometry or other parameters later
+    // (other parameters: three small blocking copies, no allocation).
+    return ensure_tables(c, &p, g, nullptr);
 }
 
 int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int rows, const lsd_params* p,
@@ -761,7 +773,9 @@ int lsd_run(lsd_ctx* c, uint8_t* map, int cols, int rows, size_t stride, const l
 }
 
 int lsd_last_region_cycles(lsd_ctx* c, int n, long long* cycles_out) {
-    if (!c || !cycles_out || n <= 0 || n > c->last_n) return LSD_ERR_INVALID;
+    // (hist_n: images of the last call whose REGION stage ran -- 0 after a call that lsd_set_stop_after ended earlier, whose counter
+    //  records would be stale or zero)
+    if (!c || !cycles_out || n <= 0 || n > c->last_n || n > c->hist_n) return LSD_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy2D(cycles_out, sizeof(long long), c->stats + kStatTotalWord, sizeof(long long) * kStatWords, sizeof(long long), (size_t)n,

@@ -34,3 +34,40 @@ def test_steady_rate_does_not_wait_for_a_crowded_queue():
 def test_steady_rate_falls_back_on_a_window_that_is_too_short():
     done = _simulate(8, 1, 100.0)
     assert abs(bench.steady_rate_ms(done, 8) - 100.0 / 8) < 1e-9
+
+
+def test_gpus_n_without_a_launcher_builds_the_drivers_command_line():
+    """`python3 bench.py --gpus 2` started like `--gpus 1` (no torch.distributed.run around it, no WORLD_SIZE): bench.py starts the
+    ranks itself as a child job before anything touches the GPU; --dry-launch prints the command it would run."""
+    import json, os, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--scaling", "strong", "--dry-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    cmd = rec["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[k + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong"]      # the launcher-only flag is gone
+    assert rec["env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "GPU_MAX_HW_QUEUES": "16"}
+
+
+def test_launch_command_is_what_the_driver_runs():
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29511",
+                       bench.__file__ if bench.__file__.startswith("/") else cmd[10], "--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_steps_in_flight_follow_the_free_hbm():
+    slot = 22.2e9
+    assert bench.fit_depth(8, slot, 2e9, 280e9) == (8, None)
+    d, note = bench.fit_depth(8, slot, 2e9, 100e9)
+    assert d == 4 and "4 in flight" in note
+    d, note = bench.fit_depth(8, slot, 2e9, 50e9)
+    assert d == 2 and note
+    assert bench.fit_depth(1, slot, 2e9, 1e9) == (1, None)
+    d, _ = bench.fit_depth(8, slot, 2e9, 1e9)
+    assert d == 1

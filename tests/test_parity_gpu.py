@@ -131,6 +131,75 @@ def test_matlab_golden_files_directly(maps, lsdmod, ctx):
     assert (matched, hits) == (36, 3865)
 
 
+def test_front_end_only_on_map1(maps, lsdmod, ctx, oracle):
+    """BASELINE.json configs[1]: mapValue_map1 with the FRONT END on the GPU only (remap + Gaussian + gradient / level-line angle /
+    pseudo-ordering; lsd_set_stop_after) -- what a caller that keeps the region stage on the host would take from the library.
+    Every array the region stage reads is the oracle's: GaussImage, magMap, maxGrad and the sorted seed list bit for bit, degMap
+    to 1 ulp, the threshold flags; no region code has run (no pixel of code 2 or 3, no line)."""
+    img = maps["map1"]
+    ref_map = img.copy()
+    d = oracle.lsd(ref_map, debug=True)["dbg"]
+    w, h = d["w"], d["h"]
+    try:
+        ctx.set_stop_after(lsdmod.STAGE_SORT)
+        got_map = img.copy()
+        lines, line_im = ctx.run(got_map)
+        assert len(lines) == 0 and not line_im.any()
+        assert np.array_equal(got_map, ref_map)                               # the in-place remap is part of the front end (myLSD.cpp:135-142)
+        assert np.array_equal(ctx.fetch(0, lsdmod.DBG_GAUSS, (w, h)), d["gauss"])
+        assert np.array_equal(ctx.fetch(0, lsdmod.DBG_MAG, (w, h)), d["mag"])
+        assert ctx.fetch(0, lsdmod.DBG_MAXGRAD, (w, h)) == d["maxGrad"]
+        assert ulps(ctx.fetch(0, lsdmod.DBG_DEG, (w, h)), d["deg"]).max() <= DEG_ULP
+        order = ctx.fetch(0, lsdmod.DBG_ORDER, (w, h)).astype(np.int64)
+        assert len(order) == d["nb"] == ctx.fetch(0, lsdmod.DBG_NB, (w, h))
+        assert np.array_equal(order, d["ord_y"].astype(np.int64) * w + d["ord_x"])
+        assert np.array_equal(ctx.fetch(0, lsdmod.DBG_ORDER_VAL, (w, h)), d["ord_v"])
+        code = (ctx.fetch(0, lsdmod.DBG_STATE, (w, h)) & 3).astype(np.uint8)
+        thr = 2.0 / np.sin(22.5 / 180.0 * np.pi)                                # myLSD.cpp:148-149, :165
+        below = d["mag"] < thr
+        below[0, :] = False; below[:, 0] = False                                # row 0 / column 0 stay 0 (Q3)
+        assert np.array_equal(code == 1, below) and not (code >= 2).any()
+        # ... and the gradient stage alone (stop after 2): the same Gaussian and magnitudes, no seed list asked for
+        ctx.set_stop_after(lsdmod.STAGE_GRAD)
+        ctx.run(img.copy())
+        assert np.array_equal(ctx.fetch(0, lsdmod.DBG_MAG, (w, h)), d["mag"])
+        assert ctx.fetch(0, lsdmod.DBG_MAXGRAD, (w, h)) == d["maxGrad"]
+    finally:
+        ctx.set_stop_after(lsdmod.STAGE_ALL)
+    lines, _ = ctx.run(img.copy())                                            # the switch leaves nothing behind
+    assert len(lines) == 7
+
+
+def test_reference_maps_as_batches_match_oracle(maps, lsdmod, ctx, oracle):
+    """bench.py's `real_maps` workload (the reference's seven maps as they are, LSD/main_on_windows.cpp:20-46, and the 2048^2 canvas of
+    three different maps pasted side by side), each as a resident batch of copies through the device entry point: every copy's line
+    count, records and lineIm are the oracle's for that map."""
+    import torch
+    import bench
+    reps = 96
+    todo = [(k, maps[k]) for k in bench.REAL_MAPS] + [("pasted2048", bench.make_pasted(maps, 2048))]
+    for name, im in todo:
+        ref = oracle.lsd(im.copy())
+        rows, cols = im.shape
+        d_maps = torch.from_numpy(np.broadcast_to(im, (reps, rows, cols)).copy()).cuda()
+        max_lines = 512
+        d_lines = torch.zeros((reps, max_lines, 10), dtype=torch.int64, device="cuda")
+        d_counts = torch.zeros(reps, dtype=torch.int32, device="cuda")
+        d_ims = torch.zeros((reps, rows, cols), dtype=torch.uint8, device="cuda")
+        ctx.enqueue_device(d_maps.data_ptr(), reps, cols, rows, d_lines.data_ptr(), max_lines, d_counts.data_ptr(),
+                           d_line_ims=d_ims.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        counts = d_counts.cpu().numpy()
+        assert (counts == len(ref["lines"])).all(), (name, counts.min(), counts.max(), len(ref["lines"]))
+        ref_im = torch.from_numpy(ref["lineIm"]).cuda()
+        assert bool((d_ims == ref_im[None]).all().item()), name
+        raw = d_lines[:, :counts[0]].cpu().numpy()
+        got0 = raw[0].copy().view(np.uint8).reshape(-1, 80).view(lsdmod.LINE_DTYPE).reshape(-1)
+        assert_lines_close(got0, ref["lines"])
+        assert all(raw[i].tobytes() == raw[0].tobytes() for i in range(1, reps)), name
+        del d_maps, d_lines, d_counts, d_ims
+
+
 def test_tile2048_parity_and_known(maps, known, lsdmod, ctx, oracle):
     img = tile2048(maps["aisle1"])
     lines, line_im, _ = full_check(lsdmod, ctx, oracle, img)
