@@ -547,6 +547,7 @@ def main():
                 traffic = None
         # per-image cycles of the region stage (s_memtime, read after the timed region): the batch time is its heaviest images
         stats = [ctx.fetch(i, lsd.DBG_STATS, (w, h)) for i in range(n)]
+        ties = ctx.last_sensitivity(n)                      # decisions within the noise of the reference's libm, per image (lsd_last_sensitivity)
         cyc = np.array([x["cycles_total"] for x in stats], np.float64)
         nb_mean = float(np.mean([ctx.fetch(i, lsd.DBG_NB, (w, h)) for i in range(0, n, max(1, n // 32))]))
         # SURVEY 8d algorithmic bytes of the whole path per image: K1 W*H + 8wh, K2 25wh, K3 8wh + 12 nb, K5 W*H (K4: latency-bound, none)
@@ -579,6 +580,9 @@ def main():
                                                      "note": "lsd_set_cost_history(1): the same batch again, its images started in the order of their cost in the previous "
                                                              "step (a caller re-extracting one site's maps); rank 0's clock, not part of `value`"} if hist_dt else None),
             "lines_per_s": total_lines / step_s, "lines_per_step": total_lines, "line_overflow_images": overflow,
+            # images of rank 0's batch with at least one decision inside the libm's noise (lsd_last_sensitivity): on the others any libm within
+            # one ulp of correct rounding gives the reference's result; and the number of such decisions over the batch
+            "libm_sensitive_images": int((ties > 0).sum()), "libm_near_ties": int(ties.sum()),
             # N > 1 only: the same --batch images split over the ranks (the strong split), timed like the weak job right after it
             "strong_split": ({"scaling": "strong", "images_total": a.batch, "ms_per_step": strong_dt / a.steps * 1e3,
                               "value": a.batch * size * size / 1e6 / (strong_dt / a.steps), "unit": "Mpix/s", "steps": a.steps,

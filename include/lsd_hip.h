@@ -131,6 +131,18 @@ int lsd_shard_balanced(const long long *costs, int n_items, int world, int *perm
  * the region stage on at least n images (lsd_set_stop_after). */
 int lsd_last_region_cycles(lsd_ctx *ctx, int n, long long *cycles_out);
 
+/* How much of the last batch's result hangs on the last place of the libm.  The reference decides with glibc's sin / cos / atan2 / exp /
+ * log10 / pow (growth test LSD/myLSD.cpp:540-543, orientation flip :655-665, density :829 / :869, Refiner's width test :845, Reducer's
+ * radius test :780, rectangle edges against pixel rows :973-1004, aligned count :1009-1013, RectangleImprover's comparisons of logNFA
+ * :1075-1156, the "pi -> 0" rule :170); this library evaluates the same functions correctly rounded, and glibc's results are within
+ * one ulp of those.  near_ties[i] = the number of decisions image i's evaluations took with their operands closer than that ulp can
+ * move them (speculative evaluations included: an upper bound).  0: any libm within one ulp of correct rounding gives the same
+ * decisions -- the lines, usedMap and lineIm of image i are the reference's on every such platform.  > 0: on this image a platform's
+ * libm may decide (about one random map in 4 000 differs from the glibc build in one decision; each of those has
+ * a count > 0 -- the property tools/campaign.py checks on every image).  Synchronises; LSD_ERR_INVALID if the last call did not run the
+ * region stage on at least n images. */
+int lsd_last_sensitivity(lsd_ctx *ctx, int n, int *near_ties);
+
 /* A communicator as this library sees it: who am I, how many are we, and ONE operation -- an all-gather of equally sized device
  * buffers (d_recv holds world x bytes_per_rank, rank r's bytes at r * bytes_per_rank), enqueued on `stream`, 0 on success. */
 typedef struct lsd_comm {

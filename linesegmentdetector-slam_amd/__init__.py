@@ -148,6 +148,8 @@ def load_library(path=None):
     if hasattr(L, "lsd_shard_balanced") or not os.environ.get("LSD_HIP_LIB"):      # (an A/B build with the gather entry points may predate these two)
         L.lsd_shard_balanced.restype = i; L.lsd_shard_balanced.argtypes = [vp, i, i, vp]
         L.lsd_last_region_cycles.restype = i; L.lsd_last_region_cycles.argtypes = [vp, i, vp]
+    if hasattr(L, "lsd_last_sensitivity") or not os.environ.get("LSD_HIP_LIB"):
+        L.lsd_last_sensitivity.restype = i; L.lsd_last_sensitivity.argtypes = [vp, i, vp]
     L.lsd_debug_calibrate.restype = i; L.lsd_debug_calibrate.argtypes = [vp, sz]
     L.lsd_debug_eval_math.restype = i; L.lsd_debug_eval_math.argtypes = [vp, i, vp, vp, vp, vp, sz]
     if path is None:
@@ -157,7 +159,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = ["lsd_create", "lsd_destroy", "lsd_strerror", "lsd_last_error", "lsd_default_params",
                     "lsd_abi_version", "lsd_free", "lsd_run", "lsd_run_batch", "lsd_enqueue_batch_device",
-                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_set_cost_history", "lsd_shard_balanced", "lsd_last_region_cycles", "lsd_set_host_max_lines",
+                    "lsd_reserve", "lsd_synchronize", "lsd_scaled_size", "lsd_set_stop_after", "lsd_set_trace", "lsd_set_region_waves", "lsd_set_region_help", "lsd_debug_set_stamp_budget", "lsd_debug_set_tuning", "lsd_set_cost_history", "lsd_shard_balanced", "lsd_last_region_cycles", "lsd_last_sensitivity", "lsd_set_host_max_lines",
                     "lsd_debug_fetch", "lsd_last_timings", "lsd_debug_eval_math", "lsd_debug_calibrate", "lsd_map_cache",
                     "lsd_enqueue_map_cache_device", "lsd_occupancy_to_map", "lsd_enqueue_occupancy_to_map_device",
                     "lsd_scan_to_map_match", "lsd_enqueue_scan_to_map_match_device",
@@ -389,6 +391,13 @@ class Context:
         self._chk(self.L.lsd_last_region_cycles(self.h, n, a.ctypes.data))
         return a
 
+    def last_sensitivity(self, n):
+        """lsd_last_sensitivity: per image of the last batch, the number of decisions taken within the noise of the reference's libm
+        (0: the image's result is the reference's under any libm within one ulp of correct rounding)."""
+        a = np.zeros(n, np.int32)
+        self._chk(self.L.lsd_last_sensitivity(self.h, n, a.ctypes.data))
+        return a
+
     def timings(self):
         ms = (C.c_float * 6)()
         self._chk(self.L.lsd_last_timings(self.h, ms))
@@ -457,7 +466,7 @@ class Context:
                           "cycles_nfa", "cycles_mark", "small_bails", "wait_noslot", "seeds", "exact_angle_evals",
                           "tile_fetches", "batches", "cycles_tiles", "spec_redos", "spec_discards", "cycles_wait", "small_steps",
                           "refill_rounds", "cycles_eval", "cycles_sums", "cycles_refine", "cycles_small", "cycles_select", "cycles_commit",
-                          "wait_noseed", "requeued_ahead", "cycles_eval_at_cursor", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "help_exports", "help_evals", "help_reclaims",
+                          "wait_noseed", "requeued_ahead", "cycles_eval_at_cursor", "depth_end", "nfa_min_abs_enc", "nfa_min_gap_enc", "help_exports", "help_evals", "near_ties",
                           "wd_commit", "wd_next", "wd_nseeds", "wd_state", "wd_nbig", "wd_lock", "wd_pend", "wd_wave"),
                          [int(x) for x in v]))
             d["set_answers"], d["sets_founded"] = int(v[41]), int(v[42])   # evaluations answered by a certified uniform set / sets founded (k_region.hip)

@@ -38,7 +38,7 @@ constexpr int CAP = 256;
 __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gauss, double* __restrict__ mag,
                                                  double* __restrict__ deg, double2* __restrict__ sc,
                                                  uint32_t* __restrict__ pw,
-                                                 unsigned long long* __restrict__ maxbits, int w, int h, int gp,
+                                                 unsigned long long* __restrict__ maxbits, int32_t* __restrict__ ties, int w, int h, int gp,
                                                  double gradThre, unsigned gx, unsigned gy, unsigned strips) {
     __shared__ uint32_t l_px[CAP];           // (strip-local pixel index << 1) | growable
     __shared__ double2 l_g[CAP];             // in: (gradX, gradY) of the listed pixel; out: (angle, -)
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
             const double2 gr = l_g[i];
             double d;                                          // :169 (first stage inline, second stage out of line: devmath.h)
             if (!crm::atan2_fast(gr.x, -gr.y, d)) d = atan2_g(gr.x, -gr.y);
+            if (fabs(fabs(d - kPi) - 0.000001) <= 1e-14) atomicAdd(&ties[img], 1);   // within an ulp of atan2 of the rule's threshold: a decision another libm could take differently (lsd_last_sensitivity)
             if (fabs(d - kPi) < 0.000001) d = 0;               // :170-171
             l_g[i] = make_double2(d, 0.0);
             if (e & 1u) {                                      // sin/cos(deg) for RegionGrower (:545-546)
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(GX) void k_gradient(const double* __restrict__ gaus
 
 void launch_gradient(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     const unsigned gx = (g.w + GX - 1) / GX, gy = (g.h + GR - 1) / GR, strips = gx * gy * (unsigned)n;
-    hipLaunchKernelGGL(k_gradient, dim3(((strips + 7u) >> 3) * 8u), dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits,
+    hipLaunchKernelGGL(k_gradient, dim3(((strips + 7u) >> 3) * 8u), dim3(GX), 0, s, b.gauss, b.mag, b.deg, b.sc, b.pw, b.maxbits, b.ties,
                        g.w, g.h, g.gp, g.gradThre, gx, gy, strips);
 }
 

@@ -143,8 +143,9 @@ struct RCtx {
 enum { ST_GROW = 0, ST_GROWN, ST_NFA, ST_RRR, ST_RRRPASS, ST_SENT, ST_OOB, ST_TREFILL, ST_TOTAL, ST_TGROW, ST_TRECT, ST_TNFA,
        ST_TMARK, ST_SMALLBAIL, ST_WNOSLOT, ST_SEEDS, ST_EXACT, ST_WRING, ST_BATCHES, ST_TTILES, ST_REDO, ST_DISCARD,
        ST_WAIT, ST_SMALLSTEPS, ST_SLOW, ST_TEVAL, ST_TSUMS, ST_TREFINE, ST_TSMALL, ST_TSELECT, ST_TCOMMIT, ST_WNOSEED,
-       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_XRECL, ST_NFASLOW, ST_SETHIT, ST_SETNEW, ST_NFACNT, ST_NFAITER, ST_COUNT };
+       ST_DEPTHUP, ST_DEPTHDN, ST_DEPTHEND, ST_MINNFA, ST_MINGAP, ST_XEXP, ST_XHELP, ST_TIES, ST_NFASLOW, ST_SETHIT, ST_SETNEW, ST_NFACNT, ST_NFAITER, ST_COUNT };
 static_assert(ST_TOTAL == kStatTotalWord, "lsd_last_region_cycles reads this word");
+static_assert(ST_TIES == kStatTiesWord, "lsd_last_sensitivity reads this word");
 // STAT: the few per-region counters the parity tests and the bench read (always on).  DSTAT / NOW(): per-batch counters and
 // s_memtime stopwatches of the developer build (make STATS=1): they cost ~10 % of the kernel, so the product build has none.
 // (every active lane adds the same value to the same word -- no lane-0 branch: a lane-dependent branch whose join block
@@ -154,10 +155,10 @@ constexpr int kStatSlots = ST_COUNT;
 __device__ constexpr int sslot(int i) { return i; }
 #else
 // the product build keeps the always-on counters only (LDS is the scarce resource of this kernel)
-constexpr int kStatSlots = 18;
+constexpr int kStatSlots = 19;
 __device__ constexpr int sslot(int i) {
     return i == ST_GROW ? 0 : i == ST_GROWN ? 1 : i == ST_NFA ? 2 : i == ST_RRR ? 3 : i == ST_RRRPASS ? 4 : i == ST_SENT ? 5 : i == ST_OOB ? 6 :
-           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : i == ST_XEXP ? 14 : i == ST_XHELP ? 15 : i == ST_SETHIT ? 16 : i == ST_SETNEW ? 17 : 11;
+           i == ST_TOTAL ? 7 : i == ST_SEEDS ? 8 : i == ST_REDO ? 9 : i == ST_DISCARD ? 10 : i == ST_MINNFA ? 12 : i == ST_MINGAP ? 13 : i == ST_XEXP ? 14 : i == ST_XHELP ? 15 : i == ST_SETHIT ? 16 : i == ST_SETNEW ? 17 : i == ST_TIES ? 18 : 11;
 }
 #endif
 #define STAT(i, v) do { g_stat[c.wave][sslot(i)] += (unsigned long long)(v); } while (0)
@@ -166,6 +167,32 @@ __device__ constexpr int sslot(int i) {
 // that the zero-initialised counters work with max (tests/test_parity_gpu.py::test_nfa_decisions_are_far_from_ties)
 #define STATMAX(i, v) do { const unsigned long long n_ = (v); if (n_ > g_stat[c.wave][sslot(i)]) g_stat[c.wave][sslot(i)] = n_; } while (0)
 constexpr unsigned long long kInfBits = 0x7ff0000000000000ull;
+// ... and ST_TIES: the number of DECISIONS this image's evaluations took within the noise of the reference's libm (lsd_last_sensitivity,
+// include/lsd_hip.h).  The reference's accept / reject decisions hang on glibc's sin / cos / atan2 / exp / log10 / pow, which differ from the
+// correctly rounded values computed here by at most one ulp.  A decision "a < b" whose operands are closer than what those ulps can
+// move them could come out differently under another libm; each such decision adds one.  0 for an image: every libm within one ulp
+// yields the same decisions, hence the same usedMap and lines.  The bounds (upper bounds of the operands' noise, generous: a false
+// count costs nothing but information):
+//   kTieAng    angles: regDeg = atan2(sum sin, sum cos) of n libm terms -> (n / |V|) 6e-16 + 1e-15 (grow()'s exact test adds n / |V|)
+//   kTieFlip   OrientationGetter's comparison of the inertia angle with regDeg (:655-665) and Refiner's wraps
+//   kTieRel    the density of a rectangle against denThre, distances against the rectangle's width / Reducer's radius (relative)
+//   kTieCoord  a rectangle edge against a pixel row / column (:973-1004), relative: a corner is c + t (dx, dy) with t up to the rectangle's
+//              length and (dx, dy) a few ulps of sin / cos off, so it moves by kTieCoord (|c| + length); an edge's height in a column by
+//              that times (1 + |slope|) -- the END edges of a rectangle that is almost axis-parallel are steep
+// A rectangle whose direction is EXACTLY axis-parallel (min(|dx|, |dy|) < 1e-15: inertiaDeg is 0, pi or +-pi/2 to the last bit, which
+// every libm returns alike, and a cosine of 6e-17 moves nothing) has libm-independent coordinates: its exact ties -- edges on pixel
+// rows are the rule there -- are not counted.
+constexpr double kTieAng = 1e-15, kTieFlip = 1e-13, kTieRel = 1e-12, kTieCoord = 4e-15;
+// (developer: -DLSD_TIE_SITES makes the counter a decimal record of WHERE the ties are: three digits per site, see the call sites)
+#ifdef LSD_TIE_SITES
+__device__ constexpr unsigned long long tie_weight(int site) { unsigned long long w = 1; for (int i = 0; i < site; i++) w *= 1000ull; return w; }
+#define TIE_UNIT(site) tie_weight(site)
+#else
+#define TIE_UNIT(site) 1ull
+#endif
+#define TIES_AT(site, v) STAT(ST_TIES, (unsigned long long)(v) * TIE_UNIT(site))
+enum { TS_GROW = 0, TS_FLIP, TS_DENS, TS_DIST, TS_EDGE, TS_ALIGN, TS_NFA };
+__device__ __forceinline__ bool axis_exact(double dx, double dy) { return fmin(fabs(dx), fabs(dy)) < 1e-15; }
 #ifdef LSD_REGION_STATS
 #define DSTAT(i, v) STAT(i, v)
 #define NOW() ((long long)__builtin_amdgcn_s_memtime())
@@ -761,7 +788,17 @@ __device__ __noinline__ int grow(int cw_, int sx_, int sy_, double regDeg0_, dou
                         exact_sums(c.wave, n);
                         const double R = n == 1 ? regDeg0 : atan2_g(g_ws[wave].ex_sin, g_ws[wave].ex_cos);   // :547 (regDeg is the seed's angle until the first accept)
                         DSTAT(ST_EXACT, 1);
-                        decided = uni(angle_diff(R, c.deg[ql]) < tol ? 1 : 0);              // :540-543
+                        const double dq = c.deg[ql], adq = angle_diff(R, dq);
+                        decided = uni(adq < tol ? 1 : 0);                                   // :540-543
+                        {   // within the libm's noise of the tolerance, or of the wrap at 3 pi / 2?  (tol == 0 and equal angles: an exact 0 < 0 on any libm)
+                            const double es = g_ws[wave].ex_sin, ec = g_ws[wave].ex_cos;
+                            const double nz = kTieAng * (1.0 + (n == 1 ? 0.0 : (double)n / fmax(sqrt(es * es + ec * ec), 1e-300)));
+                            // (the wrap at 3 pi / 2 (:541) maps a difference that fails to one of pi / 2, which fails as well unless tol reaches a quarter turn)
+                            // (angles that are 0, +-pi/2 or +-pi to the last bit -- axis-parallel walls -- are the same constants on every libm)
+                            const bool quarters = (R == 0.0 || fabs(R) == kPi / 2.0 || fabs(R) == kPi) && (dq == 0.0 || fabs(dq) == kPi / 2.0 || fabs(dq) == kPi);
+                            const bool tie = !quarters && ((fabs(adq - tol) <= nz && !(tol == 0.0 && adq == 0.0)) || (tol > 1.5 && fabs(fabs(R - dq) - kPi * 3 / 2.0) <= nz));
+                            TIES_AT(TS_GROW, uni(tie ? 1 : 0));
+                        }
                     }
                     if (decided == 1) {
                         if (lane == l) {
@@ -961,6 +998,7 @@ __device__ __noinline__ void rect_convert(int cw_, int num, double regdeg, doubl
     while (regDif <= -kPi) regDif += 2 * kPi;
     while (regDif > kPi) regDif -= 2 * kPi;
     if (regDif < 0) regDif = -regDif;
+    TIES_AT(TS_FLIP, fabs(regDif - tol) <= kTieFlip ? 1 : 0);     // (the wraps above are continuous in |regDif|: no decision)
     if (regDif > tol) inertiaDeg += kPi;
 
     double dx, dy;
@@ -1018,6 +1056,8 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
     const int lane = c.lane;
     STAT(ST_RRR, 1);
     double den = rec_density(num, g_ws[c.wave].rec);
+    const bool axis0 = axis_exact(g_ws[c.wave].rec.dx, g_ws[c.wave].rec.dy);
+    // (the comparison with denThre here repeats the caller's, which has counted its tie; the ones after a refit are counted below)
     if (den > denThre) return num;                                                 // :760
     // keep the grow-order list for the marking loops before it gets reordered
     for (int k2 = lane; k2 < num; k2 += 64) c.gcopy[k2] = lget(c, k2);
@@ -1052,7 +1092,9 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                 const uint32_t pkx = valid ? lget(c, idx) : 0u;
                 const int px = (int)(pkx & 0xffffu), py = (int)(pkx >> 16);
                 const double ddx = sx - px, ddy = sy - py;
-                const bool far = valid & (sqrt(ddx * ddx + ddy * ddy) > rad);      // :780
+                const double dist = sqrt(ddx * ddx + ddy * ddy);
+                const bool far = valid & (dist > rad);                             // :780
+                if (!axis0) TIES_AT(TS_DIST, __builtin_popcountll(ballot64(valid & (fabs(dist - rad) <= kTieRel * (1.0 + rad)))));   // (rad derives from the rectangle's corners)
                 const unsigned long long nearm = ballot64(valid & !far);
                 msk[ci] = nearm;                           // (all lanes, same value)
                 K += __builtin_popcountll(nearm);
@@ -1095,6 +1137,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
             if (!removed_any) STAT(ST_OOB, 1);             // the reference reads out of bounds here (UB): no removal
             else {
                 const double ddx = sx, ddy = sy;
+                if (!axis0) TIES_AT(TS_DIST, fabs(sqrt(ddx * ddx + ddy * ddy) - rad) <= kTieRel * (1.0 + rad) ? 1 : 0);
                 if (sqrt(ddx * ddx + ddy * ddy) > rad) {
                     if (lane == 0) tm_clear(c, 0, 0);      // curMap(0, 0) = 0
                     num--;                                 // the last point is dropped from the list (its curMap bit stays)
@@ -1114,6 +1157,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
                 px = (int)(pkx & 0xffffu); py = (int)(pkx >> 16);
             }
             const double ddx = sx - px, ddy = sy - py;
+            if (!axis0) TIES_AT(TS_DIST, fabs(sqrt(ddx * ddx + ddy * ddy) - rad) <= kTieRel * (1.0 + rad) ? 1 : 0);
             if (sqrt(ddx * ddx + ddy * ddy) > rad) {                               // :780
                 if (lane == 0) {
                     tm_clear(c, px, py);                                           // curMap = 0 (:781)
@@ -1131,6 +1175,7 @@ __device__ __noinline__ int radius_reduce_impl(int cw_, int sx, int sy, int num,
         if (num < 2) return -(num + 1);                                            // :792
         rect_convert(c.wave, num, regdeg, rec.p, rec.pk, rec.prec);                     // :797 (p, prec unchanged)
         den = rec_density(num, g_ws[c.wave].rec);
+        TIES_AT(TS_DENS, (fabs(den - denThre) <= kTieRel * denThre && !axis_exact(g_ws[c.wave].rec.dx, g_ws[c.wave].rec.dy)) ? 1 : 0);       // :775
     }
     return num;
 }
@@ -1187,6 +1232,13 @@ __device__ __forceinline__ int nfa_count(const RCtx& c, const Rec& rec, const do
     int all = 0;
     #pragma unroll
     for (int q = 0; q < NP; q++) ali[q] = 0;
+    // decisions within the libm's noise (ST_TIES): a corner or an edge within kTieCoord of a pixel column / row (not for rectangles that
+    // are axis-parallel to the last bit: their coordinates do not depend on the libm), a pixel's angle within kTieAng-ish of the precision
+    const bool axis0 = axis_exact(rec.dx, rec.dy);
+    const double ex_ = rec.x2 - rec.x1, ey_ = rec.y2 - rec.y1;
+    const double cnz = kTieCoord * (fabs(rec.x1) + fabs(rec.y1) + fabs(ex_) + fabs(ey_) + rec.wid + 1.0);     // what the libm's last place can move a corner
+    int ties_a = 0;
+    int ties = (lane == 0 && !axis0 && (fabs(vx0 - rint(vx0)) <= cnz || fabs(vx2 - rint(vx2)) <= cnz)) ? 1 : 0;   // (per lane; summed over the wave below)
     // per-column scan results of one 64-column block; the sweep worklists are free while a rectangle is being rated
     int* const s_incl = reinterpret_cast<int*>(G_WL(c.wave));
     int* const s_lo = s_incl + 64;
@@ -1197,10 +1249,18 @@ __device__ __forceinline__ int nfa_count(const RCtx& c, const Rec& rec, const do
         if (i < xlen) {
             xr = cvt_x86(i + cx0);                                                 // :976
             int yLow, yHigh;
-            if (xr < vx3) yLow = cvt_x86(ceil(vy0 + (xr - vx0) * k3));             // :988-989
-            else          yLow = cvt_x86(ceil(vy3 + (xr - vx3) * k2));             // :992-993
-            if (xr < vx1) yHigh = cvt_x86(floor(vy0 + (xr - vx0) * k0));           // :998-999
-            else          yHigh = cvt_x86(floor(vy1 + (xr - vx1) * k1));           // :1002-1003
+            const double eLow = xr < vx3 ? vy0 + (xr - vx0) * k3 : vy3 + (xr - vx3) * k2;     // :988-989 / :992-993
+            const double eHigh = xr < vx1 ? vy0 + (xr - vx0) * k0 : vy1 + (xr - vx1) * k1;    // :998-999 / :1002-1003
+            yLow = cvt_x86(ceil(eLow));
+            yHigh = cvt_x86(floor(eHigh));
+            const double kLow = xr < vx3 ? k3 : k2, kHigh = xr < vx1 ? k0 : k1;
+            if (!axis0 && (fabs(eLow - rint(eLow)) <= cnz * (1.0 + fabs(kLow)) || fabs(eHigh - rint(eHigh)) <= cnz * (1.0 + fabs(kHigh)) ||
+                           fabs(xr - vx3) <= cnz || fabs(xr - vx1) <= cnz)) {
+                ties++;
+#ifdef LSD_TIE_PRINT
+                printf("edge tie: xr %d eLow %.17g eHigh %.17g vx0 %.17g vx1 %.17g vx3 %.17g dx %.17g dy %.17g wid %.17g x1 %.17g y1 %.17g\n", xr, eLow, eHigh, vx0, vx1, vx3, rec.dx, rec.dy, rec.wid, rec.x1, rec.y1);
+#endif
+            }
             if (xr >= 0 && xr < xLim) {                                            // :1007
                 lo = yLow < 0 ? 0 : yLow;
                 const int hi = yHigh > yLim - 1 ? yLim - 1 : yHigh;
@@ -1227,10 +1287,18 @@ __device__ __forceinline__ int nfa_count(const RCtx& c, const Rec& rec, const do
                 const int j = s_lo[ci] + (t - ex);
                 df = angle_diff(rec.deg, c.deg[(size_t)j * xLim + s_x[ci]]);       // :1009-1011
             }
+            bool near = false;
             #pragma unroll
-            for (int q = 0; q < NP; q++) ali[q] += __builtin_popcountll(ballot64(df < prec[q]));   // :1012-1013
+            for (int q = 0; q < NP; q++) {
+                ali[q] += __builtin_popcountll(ballot64(df < prec[q]));            // :1012-1013
+                near = near || fabs(df - prec[q]) <= 4.0 * kTieAng;                // (two angles of an ulp each)
+            }
+            if (near) ties_a++;
         }
     }
+    for (int off = 32; off >= 1; off >>= 1) { ties += __shfl_xor(ties, off); ties_a += __shfl_xor(ties_a, off); }
+    TIES_AT(TS_EDGE, ties);
+    TIES_AT(TS_ALIGN, ties_a);
     PSTAT(ST_NFACNT, NOW() - t00);
     return all;
 }
@@ -1311,10 +1379,13 @@ __device__ __noinline__ double improve(int cw_) {
         if (fabs(v) <= 1.7976931348623157e308) {
             const double nv = 0x1p-51 * fabs(v + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(v), c.logNT));
             if (!host_only) STATMAX(ST_MINNFA, kInfBits - (unsigned long long)__double_as_longlong(fabs(v) / nv));       // (v is compared with 0: :1075, :242)
+            int tie = (!host_only && fabs(v) / nv < 2.0) ? 1 : 0;              // (the campaigns' floor: a margin below 1 can flip, below 2 is counted)
             if (!first && v != bestNFA) {
                 const double nb = 0x1p-51 * fabs(bestNFA + c.logNT) + 0x1p-52 * (1.0 + fmax(fabs(bestNFA), c.logNT));
                 STATMAX(ST_MINGAP, kInfBits - (unsigned long long)__double_as_longlong(fabs(v - bestNFA) / (nv + nb)));
+                if (fabs(v - bestNFA) / (nv + nb) < 2.0) tie++;
             }
+            TIES_AT(TS_NFA, tie);
         }
     };
     {   // :1075-1079
@@ -1386,9 +1457,10 @@ __device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, doub
     const int lane = c.lane, w = c.w;
     [[maybe_unused]] const long long t0 = NOW();
     const double rwid = g_ws[c.wave].rec.wid;
+    const bool axis0 = axis_exact(g_ws[c.wave].rec.dx, g_ws[c.wave].rec.dy);
     const int wave = __builtin_amdgcn_readfirstlane(c.wave);
     double S = 0;                                 // serial accumulation in list order: lane 0 difSum, 1 squSum
-    int ptNum = 0;
+    int ptNum = 0, ties = 0;
     for (int base = 0; base < num; base += 64) {                                   // :839-853
         const int kx = base + lane;
         bool flag = false;
@@ -1397,9 +1469,12 @@ __device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, doub
             const uint32_t pkx = lget(c, kx);
             const int x = (int)(pkx & 0xffffu), y = (int)(pkx >> 16);
             const double ddx = sx - x, ddy = sy - y;
-            if (sqrt(ddx * ddx + ddy * ddy) < rwid) {
+            const double dist = sqrt(ddx * ddx + ddy * ddy);
+            if (!axis0 && fabs(dist - rwid) <= kTieRel * (1.0 + rwid)) ties++;    // :845 within the noise of the rectangle's width
+            if (dist < rwid) {
                 flag = true;
                 degDif = c.deg[(size_t)y * w + x] - cenDeg;
+                if (fabs(fabs(degDif) - kPi) <= kTieFlip) ties++;                  // :848-851 (two map angles half a turn apart)
                 while (degDif <= -kPi) degDif += 2 * kPi;
                 while (degDif > kPi) degDif -= 2 * kPi;
             }
@@ -1416,6 +1491,8 @@ __device__ __noinline__ double refine_tol(int cw_, int sx, int sy, int num, doub
             S = acc32(wave, lane, cnt, S);
         }
     }
+    for (int off = 32; off >= 1; off >>= 1) ties += __shfl_xor(ties, off);
+    TIES_AT(TS_DIST, ties);
     const double difSum = rl(S, 0), squSum = rl(S, 1);
     const double meanDif = difSum / (ptNum * 1.0);
     PSTAT(ST_TREFINE, NOW() - t0);
@@ -1670,6 +1747,8 @@ __device__ __noinline__ void eval_seed(int cw_, uint32_t pp_, int spec_, int slo
             else regdeg = seedDeg;
             rect_convert(wave, num, regdeg, p_aliPro, 0, p_degThre);                   // :232 / :866 (p, prec still the defaults)
             const double den = uni(rec_density(num, g_ws[wave].rec));
+            if (fabs(den - p_denThre) <= kTieRel * p_denThre && !axis_exact(g_ws[wave].rec.dx, g_ws[wave].rec.dy))     // :829 / :869 within the libm's noise
+                g_stat[wave][sslot(ST_TIES)] += TIE_UNIT(TS_DENS);
             if (pass == 0) {
                 if (den >= p_denThre) break;                                      // :829 dense enough
                 sparse_by_margin = den < p_denThre * (1.0 - 1e-3);
@@ -2322,7 +2401,6 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
         if (lane == 0) won = atomicCAS(&xr[kXReq + j], (uint32_t)(f0 + 1), 0u) == (uint32_t)(f0 + 1) ? 1 : 0;
         if (__builtin_amdgcn_readfirstlane(won)) {
             if (lane == 0) { s_xk[j] = -1; atomicSub(&s_xout, 1); st_st(&rg.state[r], R_REDO); }
-            DSTAT(ST_XRECL, 1);
             moved = true;
         }
         return moved;
@@ -2831,6 +2909,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             else atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
         }
         g_stat[c.wave][sslot(ST_XHELP)] = 0ull;
+        // (what a helper adds to ANOTHER image's record below starts from zero: not from this image's own margins and ties)
+        g_stat[c.wave][sslot(ST_MINNFA)] = 0ull; g_stat[c.wave][sslot(ST_MINGAP)] = 0ull; g_stat[c.wave][sslot(ST_NFASLOW)] = 0ull; g_stat[c.wave][sslot(ST_TIES)] = 0ull;
     }
     if (!b.xq) return;
     if (wave == 0 && !pool) {
@@ -2955,8 +3035,9 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
             unsigned long long* const hs = reinterpret_cast<unsigned long long*>(b.stats + (size_t)hx * kStatWords);
             atomicMax(&hs[ST_MINNFA], g_stat[c.wave][sslot(ST_MINNFA)]); atomicMax(&hs[ST_MINGAP], g_stat[c.wave][sslot(ST_MINGAP)]);
             atomicAdd(&hs[ST_NFASLOW], g_stat[c.wave][sslot(ST_NFASLOW)]);
+            atomicAdd(&hs[ST_TIES], g_stat[c.wave][sslot(ST_TIES)]);
         }
-        if (b.stats) { g_stat[c.wave][sslot(ST_MINNFA)] = 0ull; g_stat[c.wave][sslot(ST_MINGAP)] = 0ull; g_stat[c.wave][sslot(ST_NFASLOW)] = 0ull; }
+        if (b.stats) { g_stat[c.wave][sslot(ST_MINNFA)] = 0ull; g_stat[c.wave][sslot(ST_MINGAP)] = 0ull; g_stat[c.wave][sslot(ST_NFASLOW)] = 0ull; g_stat[c.wave][sslot(ST_TIES)] = 0ull; }
         const EvalOut& eo = g_eo[wave];
         const bool skip = eo.skip != 0;
         const int outcome = eo.outcome, num = eo.num, num0 = eo.num0, rec_pk = eo.rec_pk;

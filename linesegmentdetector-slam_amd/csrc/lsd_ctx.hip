@@ -312,7 +312,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->order, nn));
         HIPCHK(c, re_alloc(&c->sets, nn * 256));
         HIPCHK(c, re_alloc(&c->xq, nn * (size_t)(kXStride + 1) + kXHdr));
-        HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));
+        HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, 2 * nn)); HIPCHK(c, re_alloc(&c->nseed, nn));   // (nb: [0, nn) list lengths, [nn, 2 nn) the gradient pass's near-tie counts)
         HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
@@ -558,7 +558,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     Buffers b{};
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
-    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb; b.ties = c->nb + c->cap_n;
     b.ord = c->ord; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
     b.tm_stride = 4 * ((g.w + 7) >> 3) * ((g.h + 7) >> 3);
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
@@ -585,7 +585,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
 
     HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));
     HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, s));
-    HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * n, s));
+    HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * (c->cap_n + (size_t)n), s));          // (list lengths and, from cap_n on, the near-tie counts)
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // Mat::zeros, myLSD.cpp:215: the Gaussian's tiles clear lineIm on the way where the raster is made of whole 16-byte words; else a
@@ -780,6 +780,22 @@ int lsd_last_region_cycles(lsd_ctx* c, int n, long long* cycles_out) {
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy2D(cycles_out, sizeof(long long), c->stats + kStatTotalWord, sizeof(long long) * kStatWords, sizeof(long long), (size_t)n,
                           hipMemcpyDeviceToHost));
+    return LSD_OK;
+}
+
+int lsd_last_sensitivity(lsd_ctx* c, int n, int* near_ties) {
+    if (!c || !near_ties || n <= 0 || n > c->last_n || n > c->hist_n) return LSD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    std::vector<long long> reg((size_t)n);
+    std::vector<int32_t> grad((size_t)n);
+    HIPCHK(c, hipMemcpy2D(reg.data(), sizeof(long long), c->stats + kStatTiesWord, sizeof(long long) * kStatWords, sizeof(long long), (size_t)n,
+                          hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(grad.data(), c->nb + c->cap_n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        const long long v = reg[(size_t)i] + grad[(size_t)i];
+        near_ties[i] = v > 0x7fffffffll ? 0x7fffffff : (int)v;
+    }
     return LSD_OK;
 }
 

@@ -12,6 +12,7 @@ constexpr int kMaxTapRadius = 40;               // hSize = 2*h+1 <= 81 taps per 
 constexpr int kLgTable = 16384;                 // host-tabulated log-gamma entries every context starts with; it grows to w*h + 2 (the largest
 constexpr int kLgTableMax = 1 << 23;            //    pixel count a rectangle can have, + 1), up to this many
 constexpr int kStatWords = 48;                  // counters per image of the region stage (lsd_debug_fetch LSD_DBG_STATS)
+constexpr int kStatTiesWord = 39;               // ... and this one its decisions within the libm's noise (k_region.hip: ST_TIES; lsd_last_sensitivity)
 constexpr int kStatTotalWord = 8;               // ... of which this one holds the shader clocks the stage spent on the image (k_region.hip: ST_TOTAL)
 constexpr int kPTable = 16;                     // host-tabulated log(p), log10(p), log(1-p) for p = aliPro/2^k
 // Help across workgroups in the region stage (k_region.hip): a control block of 32-bit words per launch, cleared before it.
@@ -62,6 +63,7 @@ struct Buffers {
     uint32_t* tepoch;      // n x ceil(w/8) x ceil(h/8) : per tile, epoch + 1 of the latest accepted line with a pixel in it (cleared per run)
     unsigned long long* maxbits;  // n : bit pattern of max gradient (non-negative double)
     int32_t* nb;           // n : sorted-list length
+    int32_t* ties;         // n : decisions of the gradient pass within the libm's noise (lsd_last_sensitivity; the region stage counts its own in the counter records)
     uint32_t* ord;         // n x npx : sorted seed list (y*w+x)
     uint32_t* stamps;      // n x NW x tm_stride : per wave, the member masks of the tiles its cache has evicted (4 words per 8x8 tile: grow id, -, 64 bits)
     int tm_stride;         // words per wave of the above: 4 x tiles of the scaled image

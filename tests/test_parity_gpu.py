@@ -1426,6 +1426,43 @@ def test_libm_tie_images_equal_the_correctly_rounded_restatement(name, lsdmod, c
     g = oracle.lsd(img.copy(), debug=True, **kw)                      # ... and differs from the glibc-built one (the caveat)
     same = np.array_equal(used, g["dbg"]["used"]) and np.array_equal(im, g["lineIm"])
     assert same == name.startswith("near")                            # (near*: an NFA comparison inside the libms' noise on which both builds agree)
+    # ... and the library says so itself: the image has decisions within the noise of the reference's libm (lsd_last_sensitivity);
+    # with tracing off too (the count does not depend on it)
+    assert int(ctx.last_sensitivity(1)[0]) > 0
+    ctx.run(img.copy(), lsdmod.make_params(**kw) if kw else None)
+    assert int(ctx.last_sensitivity(1)[0]) > 0 and ctx.fetch(0, lsdmod.DBG_STATS, (d["w"], d["h"]))["near_ties"] > 0
+
+
+def test_sensitivity_of_the_reference_maps_and_of_a_batch(maps, lsdmod, ctx, oracle):
+    """lsd_last_sensitivity on the reference's own maps: the count of decisions within the libm's noise is reported per image of a
+    batch, and the call fails after a run that stopped before the region stage."""
+    names = [n for n in FIXTURES if maps[n].shape == maps["aisle2"].shape]    # aisle2 / aisle3 share a size
+    batch = np.stack([maps[n] for n in names] + [maps[names[0]]])
+    ctx.run_batch(batch.copy())
+    t = ctx.last_sensitivity(len(batch))
+    assert t.dtype == np.int32 and (t >= 0).all()
+    with pytest.raises(lsdmod.LsdError):
+        ctx.last_sensitivity(len(batch) + 1)
+    counts = {}
+    for n in FIXTURES:
+        ctx.run(maps[n].copy())
+        counts[n] = int(ctx.last_sensitivity(1)[0])
+    print("near ties of the reference's maps:", counts, "in a batch:", t)
+    # (the count includes speculative evaluations that were discarded, so it is an upper bound that moves a little with the schedule;
+    #  what does not move is whether an image has any: every one of the reference's maps does -- the END edges of a rectangle pass
+    #  through the centre of the region's extreme pixel by construction, :701-720, so "which side of the edge is that pixel on"
+    #  is decided in the last places of sin / cos on nearly every map)
+    for j, n in enumerate(names):
+        assert (counts[n] > 0) == (t[j] > 0), (n, counts[n], t[j])
+    try:
+        ctx.set_stop_after(lsdmod.STAGE_SORT)
+        ctx.run(maps["map1"].copy())
+        with pytest.raises(lsdmod.LsdError):
+            ctx.last_sensitivity(1)
+        with pytest.raises(lsdmod.LsdError):
+            ctx.last_region_cycles(1)
+    finally:
+        ctx.set_stop_after(lsdmod.STAGE_ALL)
 
 
 def test_watchdog_failure_path_is_reported_not_fatal(maps, lsdmod, ctx):
