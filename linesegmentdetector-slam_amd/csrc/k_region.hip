@@ -1895,7 +1895,9 @@ __device__ __forceinline__ bool st_cas(uint8_t* base, int idx, int expect, int d
 __device__ __forceinline__ int imin8(int v) { return (int)min8((float)v); }
 __device__ __forceinline__ int imax8(int v) { return -(int)min8(-(float)v); }
 
-__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATTR void k_region(Geom g, Buffers b, uint32_t id_base) {
+// One image's region stage by the calling workgroup; `bid` is the workgroup's place in the launch's image order (blockIdx.x of the
+// one-workgroup-per-image launch; the next number of the launch's counter for a persistent workgroup, see k_region below).
+__device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, uint32_t id_base, const int bid, const int nimg) {
     __shared__ int s_next, s_commit, s_epoch, s_lines, s_ntrace, s_nseeds, s_lock, s_nbig, s_depth, s_abort, s_nsets;
     __shared__ int s_scan[NW];                              // the waves' counts of potential seeds (the seed scan at the start)
     __shared__ short s_ring[RING][4];
@@ -1908,9 +1910,8 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
 
     // The last b.npool workgroups of the launch own no image: they are HELPERS from the start (the host adds them when the images
     // leave workgroup slots of the device free, see "Help from other workgroups" below), with a workspace slot of their own.
-    const int nimg = (int)gridDim.x - b.npool;
-    const bool pool = (int)blockIdx.x >= nimg;
-    const size_t img = pool ? (size_t)blockIdx.x : (size_t)b.order[blockIdx.x];           // heaviest images first (k_order); pool: its workspace slot
+    const bool pool = bid >= nimg;
+    const size_t img = pool ? (size_t)bid : (size_t)b.order[bid];                         // heaviest images first (k_order); pool: its workspace slot
     uint32_t* const xr = (b.xq && !pool) ? b.xq + img * (size_t)kXStride : nullptr;        // this image's record of the help protocol
     uint32_t* const xhdr = b.xq ? b.xq + (size_t)nimg * kXStride : nullptr;                 // ... and the launch's
     if (threadIdx.x == 0 && xhdr && !pool) atomicAdd(&xhdr[0], 1u);
@@ -3075,6 +3076,36 @@ __global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATT
     }
     // (a helper's count of evaluations done for others goes to its own image's record)
     if (b.stats && lane == 0 && !pool) atomicAdd(reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords) + ST_XHELP, g_stat[c.wave][sslot(ST_XHELP)]);
+}
+
+// The launch.  One workgroup per image (+ b.npool helper-only workgroups), dispatched in the order of k_order -- or, on the 8-wave
+// build, PERSISTENT workgroups (b.pcount, lsd_ctx.hip: a batch of more images than the device has CUs, help off): as many workgroups
+// as CUs, each taking the next image of that order from the launch's counter until none is left.  The hardware deals the workgroups
+// of a launch onto the eight XCDs round-robin and never moves them, so with one workgroup per image an XCD whose 64 images are heavy
+// finishes last while CUs of the others idle; the counter balances across XCDs: 512 maps as one step 78.6 -> 73.4 ms
+// (profiles/r06d_scheduling_probes.log).  Not for the 4-wave build: there the loop around the image's code costs the kernel body's register
+// allocation 16 % (31.3 -> 36.4 ms per step with eight steps in flight, same log) and buys nothing (persistent workgroups let the
+// front ends of the other steps flow -- their dispatches no longer wait behind a launch that does not fit the device -- but the steps'
+// tails leave the slots of finished workgroups empty: 36.6-45.7 ms against 36.8).
+__global__ __launch_bounds__(64 * NW, LSD_REGION_WAVES_PER_SIMD) LSD_REGION_KATTR void k_region(Geom g, Buffers b, uint32_t id_base) {
+#if LSD_REGION_NW == 8
+    __shared__ int s_take;
+    while (true) {                                          // (one call site: the image's code exists once)
+        int bid = (int)blockIdx.x, nimg = (int)gridDim.x - b.npool;
+        if (b.pcount) {
+            if (threadIdx.x == 0) s_take = atomicAdd(b.pcount, 1);
+            __syncthreads();
+            bid = s_take; nimg = b.nimg;
+            __syncthreads();                                // (everybody has read it before the next round overwrites it)
+            if (bid >= nimg) return;
+        }
+        region_image(g, b, id_base, bid, nimg);
+        if (!b.pcount) return;
+        __syncthreads();                                    // every wavefront is out of the image before its shared state is set up again
+    }
+#else
+    region_image(g, b, id_base, (int)blockIdx.x, (int)gridDim.x - b.npool);
+#endif
 }
 
 }  // namespace RVAR

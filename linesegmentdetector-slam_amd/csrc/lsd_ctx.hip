@@ -98,6 +98,8 @@ struct lsd_ctx {
     bool ga_ev_valid = false;
     // options
     int stop_after = 0;
+    int tun_groups = -1;                // the 8-wave region stage as persistent workgroups (k_region.hip: k_region): -1 = as many as CUs when the batch has more images than that, 0 = never
+    int* pcount = nullptr;              // ... and the launch's image counter
     bool trace = false;
     int host_max_lines = 8192;
     // last run
@@ -375,6 +377,7 @@ static const Tuning kTunings[] = {
     {"REQUEUE", 0, 1, &lsd_ctx::tun_requeue, false},       // 0: invalidated results are found at the cursor only
     {"XPOLL", 100, 1 << 30, &lsd_ctx::tun_xpoll, false},   // clocks between two looks of a wave at the help protocol
     {"LINGER", 1, 1 << 30, &lsd_ctx::tun_linger, false},   // looks (~27 us each) a helper takes for an image that asks before it gives its CU back
+    {"GROUPS", -1, 1 << 20, &lsd_ctx::tun_groups, false},  // 8-wave region stage as persistent workgroups: -1 (default) as many as CUs when the batch has more images, 0 never, n that many
     {"STOP", 0, 1 << 30, &lsd_ctx::tun_stop, false},       // developer build of the kernel: the seed loop ends after this many seeds (probe experiment)
 };
 
@@ -467,6 +470,7 @@ void lsd_destroy(lsd_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ga_ev) (void)hipEventDestroy(c->ga_ev);
+    if (c->pcount) (void)hipFree(c->pcount);
     for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_flat) (void)hipFree(c->h_flat);
@@ -599,21 +603,30 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_SORT) { launch_sort(g, b, n, s); launch_order(b, n, g.npx, (c->cost_history && c->hist_n == n && !c->trace) ? c->stats : nullptr, s); }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
+    hipStream_t sr = s;
     if (c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION) {
         // stamps of earlier runs must never look current: every run gets its own 2^20-wide id range
         if (++c->run_id >= 1023u) {
-            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * tm_words(c->cap_npx) * sizeof(uint32_t), s));
-            HIPCHK(c, hipMemsetAsync(c->epochmap, 0, c->cap_n * c->cap_npx * sizeof(uint32_t), s));   // (the set labels carry the run number too)
+            HIPCHK(c, hipMemsetAsync(c->stamps, 0, c->cap_ws * tm_words(c->cap_npx) * sizeof(uint32_t), sr));
+            HIPCHK(c, hipMemsetAsync(c->epochmap, 0, c->cap_n * c->cap_npx * sizeof(uint32_t), sr));   // (the set labels carry the run number too)
             c->run_id = 1;
         }
-        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, s));
-        HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), s));
-        if (b.xq) HIPCHK(c, hipMemsetAsync(c->xq, 0, sizeof(uint32_t) * ((size_t)n * (kXStride + 1) + kXHdr), s));
+        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, sr));
+        HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), sr));
+        if (b.xq) HIPCHK(c, hipMemsetAsync(c->xq, 0, sizeof(uint32_t) * ((size_t)n * (kXStride + 1) + kXHdr), sr));
         // 8 wavefronts per image take a whole CU each: worth it up to four images per CU (waves_for); the per-wave workspace
         // (stamps / spill / gcopy: 12 B per scaled pixel and wave) was sized for it by ensure_workspace
         const bool wide = waves_for(c, n) == 8;
-        if (wide) launch_region_w8(g, b, n, c->run_id << 20, s);
-        else launch_region_w4(g, b, n, c->run_id << 20, s);
+        int grid = n;
+        const int groups = c->tun_groups >= 0 ? c->tun_groups : c->num_cus;
+        if (wide && groups > 0 && groups < n && !b.xq && !c->trace) {           // persistent workgroups (k_region.hip: k_region): fewer workgroups than images
+            if (!c->pcount) HIPCHK(c, hipMalloc(&c->pcount, 64));
+            HIPCHK(c, hipMemsetAsync(c->pcount, 0, sizeof(int), sr));
+            b.pcount = c->pcount; b.nimg = n; b.npool = 0;
+            grid = groups;
+        }
+        if (wide) launch_region_w8(g, b, grid, c->run_id << 20, sr);
+        else launch_region_w4(g, b, grid, c->run_id << 20, sr);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     if (c->stop_after == 0) launch_lines(g, b, n, s);
