@@ -448,7 +448,7 @@ def main():
     # protocol (barrier, K steps, barrier, max over ranks).  A shard is 1/N of the images, so a rank's GPU is 1/N as full as in the weak
     # job: DESIGN.md section 6 says what that costs and what a rank that keeps N x as many steps in flight gets back.
     strong_dt = None
-    if world > 1 and a.scaling == "weak":
+    if use_dist and a.scaling == "weak":                       # (use_dist: world > 1, or one rank under --force-dist -- the tests' way into this path)
         lo_s, hi_s = ldist.shard_range(a.batch, world, rank)
         strong_err = torch.zeros(1, dtype=torch.int32, device=dev)
         try:

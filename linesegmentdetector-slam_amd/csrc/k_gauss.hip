@@ -11,7 +11,10 @@
 
 namespace lsdhip {
 
-constexpr int TW = 32, TH = 32, NT = 256;
+#ifndef LSD_K1_TH
+#define LSD_K1_TH 32
+#endif
+constexpr int TW = 32, TH = LSD_K1_TH, NT = 256;
 
 __device__ __forceinline__ int reflect_idx(int j, int lim) {  // myLSD.cpp:436-443
     const int dou = 2 * lim;
@@ -255,7 +258,7 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, uint8_t* clr, hipStrea
     const int IWmax = span + 2 * g.tapR + 1;
     int IWp = ((IWmax + 3) & ~3) + 8;                             // + the alignment slack of the word-wise staging and of the x-pass's 5-word reads
     if (((IWp >> 2) & 1) == 0) IWp += 4;                          // odd pitch in 32-bit words: consecutive rows start in different LDS banks
-    const int IHmax = IWmax;
+    const int IHmax = (int)floor((TH - 1) / g.sca) + 2 + 2 * g.tapR + 1;   // (as IWmax, for the tile's height)
     const int hSize = 2 * g.tapR + 1;
     const size_t lds = (size_t)IHmax * TW * sizeof(double) + 3 * hSize * sizeof(double) + (size_t)IHmax * IWp;
     auto kern = hSize == 17 ? k_gauss<17> : k_gauss<0>;

@@ -988,6 +988,10 @@ def test_rccl_gather_runs_on_the_gpu(maps, lsdmod, ctx):
     assert out["n_gpus"] == 1 and out["config"]["images_total"] == 6
     lines, offs, _ = ctx.run_batch(bench.make_batch(maps, 6, 1024))
     assert int(out["lines_per_step"]) == len(lines) == int(offs[-1])
+    # the strong split timed next to the weak job (with one rank: the same six images as one shard) went through as well, and the
+    # gathered copies bench.py asserts afterwards are the weak job's again
+    ss = out["strong_split"]
+    assert ss and ss["scaling"] == "strong" and ss["images_total"] == 6 and ss["ms_per_step"] > 0
 
 
 def _fnv1a(b):
@@ -1226,7 +1230,10 @@ def test_large_batches_run_without_help_by_default(maps, lsdmod, oracle):
 
 
 @pytest.mark.parametrize("tun", [{"REQUEUE": 0}, {"SOFT": 64, "CLAIM": 64}, {"SOFT": 1900, "CLAIM": 1900, "BIG": 16},
-                                 {"HELP": 64, "WB": 100, "XPOLL": 2000}])
+                                 {"HELP": 64, "WB": 100, "XPOLL": 2000},
+                                 # the 8-wave region stage as 5 / 47 PERSISTENT workgroups that share the 48 images out through a counter
+                                 # (k_region.hip: k_region; the default takes that path for batches of more images than CUs, help off)
+                                 {"HELP": 0, "GROUPS": 5}, {"HELP": 0, "GROUPS": 47}, {"HELP": 0, "GROUPS": 0}])
 def test_schedule_of_the_region_stage_changes_nothing(tun, maps, lsdmod, ctx):
     """How far the wavefronts work ahead of the commit cursor, whether invalidated results are re-queued when a line is accepted
     or found at the cursor, who may ask for help and how often the help protocol is looked at: all of it is schedule.  A
