@@ -103,9 +103,10 @@ int lsd_set_host_max_lines(lsd_ctx *ctx, int max_lines);
  *              when (n, cols, rows) grew. */
 #define LSD_FLAG_WRITEBACK_MAP 1u
 /* Known cliff: the wavefronts of an image's workgroup evaluate different seeds; ONE region's frontier is walked by one wavefront.  An
- * image made of regions of ten thousand pixels and more (a 2000 x 1500 sawtooth of 25 bands) returns the reference's result but takes
- * 0.08 s, 1.3-2.7 x ONE host thread of the algorithm, where occupancy maps (largest region of the reference's maps: 680 pixels) run
- * 300-600 x faster than that thread.  lsd_last_region_cycles shows it: above ~500 cycles per scaled pixel an image is of this kind. */
+ * image made of regions of ten thousand pixels and more (sawtooth test images) returns the reference's result but takes 35-93 ms,
+ * 2.8-3.3 x ONE host thread of the algorithm (measured: profiles/r06g_cliff_probe.log), where occupancy maps (largest region of the
+ * reference's maps: 680 pixels) run hundreds of times faster than that thread in batches.  lsd_last_region_cycles shows it: occupancy
+ * maps cost 57-350 cycles per scaled pixel, such images 850-1000. */
 int lsd_enqueue_batch_device(lsd_ctx *ctx, uint8_t *d_maps, int n, int cols, int rows,
                              const lsd_params *p, unsigned flags, uint8_t *d_line_ims,
                              lsd_line *d_lines, int max_lines, int32_t *d_counts, void *stream);

@@ -1,7 +1,7 @@
 // k_gauss.hip -- K1: fused value remap + separable Gaussian x0.3 downsample (gfx950).
 //
 // Replaces the prologue remap (LSD/myLSD.cpp:135-142) and GaussianSampler (LSD/myLSD.cpp:378-484).
-// One workgroup produces a 32x32 tile of the scaled image: the (reflected, remapped) u8 source
+// One workgroup produces a 32x24 tile (TW x TH) of the scaled image: the (reflected, remapped) u8 source
 // window is staged in LDS with coalesced row-major loads, the x-pass writes an fp64 LDS strip,
 // the y-pass reads it back column-wise.  The reference's aux[H][w] image never exists in HBM.
 //
@@ -11,8 +11,12 @@
 
 namespace lsdhip {
 
+// Output tile: 32 wide, 24 high.  The height sets the LDS a workgroup needs (the x-pass sums of the window's rows: 38 KB at 24, 49 KB
+// at 32, 27 KB at 16) against the rows of the window that neighbouring tiles compute twice; the kernel is bound by the latency of its
+// staging, so workgroups per CU count: 32 -> 24 rows (four workgroups per CU instead of three) 2.58 -> 2.35 ms on the bench batch, 16
+// rows (five) 2.83 (profiles/r06g_k1_tile_heights.log; same bits).
 #ifndef LSD_K1_TH
-#define LSD_K1_TH 32
+#define LSD_K1_TH 24
 #endif
 constexpr int TW = 32, TH = LSD_K1_TH, NT = 256;
 
