@@ -659,6 +659,31 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - t1) * 1e3)
     out["single_image_latency_ms"] = min(lat)
+    # -- the observable in-place remap of the caller's maps (myLSD.cpp:135-142), which the timed region leaves out because its steps in
+    #    flight share one resident input (config.writeback_map): what it costs, one step at a time on a private copy of the batch
+    #    (restored before every repetition), with LSD_FLAG_WRITEBACK_MAP and without
+    try:
+        d_priv = d_maps.clone()
+        tw = {}
+        for flag in (0, lsd.LSD_FLAG_WRITEBACK_MAP):
+            ts = []
+            for _ in range(3):
+                d_priv.copy_(d_maps)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.enqueue_device(d_priv.data_ptr(), n_total, size, size, d_lines.data_ptr(), a.max_lines, d_counts.data_ptr(), d_line_ims=ims, flags=flag, stream=stream)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            tw[flag] = (min(ts), ctx.timings()["gauss"])
+        rem = ((d_maps == 1) | (d_maps == 255))
+        rem[:, 0, :] = False; rem[:, :, 0] = False
+        ok = bool(((d_priv != d_maps) == rem).all().item())      # exactly the cells with value 1 or 255 off row 0 / column 0 were rewritten
+        out["writeback_map"] = {"step_ms_without": tw[0][0], "step_ms_with": tw[lsd.LSD_FLAG_WRITEBACK_MAP][0], "gauss_ms_without": tw[0][1],
+                                "gauss_ms_with": tw[lsd.LSD_FLAG_WRITEBACK_MAP][1], "maps_rewritten_as_the_reference_does": ok,
+                                "note": "one step at a time on a private copy of the batch: the in-place remap (a1) rides on K1's event window; the timed region runs without it"}
+        del d_priv, rem
+    except (RuntimeError, lsd.LsdError) as e:
+        out["writeback_map"] = {"error": str(e)[:200]}
     # -- mapValue_map1 (608 x 480, 7 lines): (a) the reference's usage, ONE host-ABI call createMapCache + myLineSegmentDetector
     #    (LSD/main_on_windows.cpp:67-70), wall time incl. PCIe; (b) throughput on 512 replicas resident in HBM
     m1 = maps["map1"]
