@@ -8,6 +8,7 @@
 // Bit-exactness: same taps (computed on the host with the host libm), same accumulation order
 // (newVal += pix * ker[i], i ascending), fp64, no FMA contraction (-ffp-contract=off).
 #include "lsd_internal.h"
+#include <algorithm>
 
 namespace lsdhip {
 
@@ -241,7 +242,33 @@ __global__ __launch_bounds__(NT) void k_gauss(const uint8_t* __restrict__ in, do
     }
 }
 
-// Observable side effect of the reference: the caller's image is rewritten in place (myLSD.cpp:135-142).
+// Observable side effect of the reference: the caller's image is rewritten in place (myLSD.cpp:135-142): 1 -> 255, 255 -> 0 for y >= 1,
+// x >= 1.  16 bytes per lane where the rows are whole 16-byte units (the byte masks of the staging above, four words at a time), and a
+// unit is written back only if it changes -- free space is most of an occupancy map, so most units are only read: 512 maps of 2048^2
+// 3.2 -> see DESIGN.md section 5 (one byte per thread with a 64-bit division each before).
+__device__ __forceinline__ uint32_t remap_word(uint32_t x, uint32_t keep) {
+    uint32_t t1 = x ^ 0x01010101u, t2 = ~x;                   // zero bytes mark the two cases
+    t1 = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);   // 0x80 in every byte that was zero
+    t2 = ~(((t2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t2 | 0x7f7f7f7fu);
+    const uint32_t m1 = (t1 | (t1 - (t1 >> 7))) & ~keep, m255 = (t2 | (t2 - (t2 >> 7))) & ~keep;
+    return (x | m1) & ~m255;
+}
+__global__ __launch_bounds__(256) void k_remap_inplace16(uint8_t* __restrict__ img, uint32_t W, uint32_t H, size_t units) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* const v = reinterpret_cast<u32x4*>(img);
+    const uint32_t upr = W >> 4;                                  // units per row
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += stride) {
+        const u32x4 x = v[u];
+        if ((x.x | x.y | x.z | x.w) == 0u) continue;              // free space: nothing to rewrite
+        const uint32_t row = (uint32_t)(u / upr), col = (uint32_t)(u - (size_t)row * upr);
+        if (row % H == 0u) continue;                              // row 0 of an image keeps its raw values (Q2)
+        u32x4 r;
+        r.x = remap_word(x.x, col == 0u ? 0xffu : 0u);            // ... and so does column 0
+        r.y = remap_word(x.y, 0u); r.z = remap_word(x.z, 0u); r.w = remap_word(x.w, 0u);
+        if ((r.x ^ x.x) | (r.y ^ x.y) | (r.z ^ x.z) | (r.w ^ x.w)) v[u] = r;
+    }
+}
 __global__ __launch_bounds__(256) void k_remap_inplace(uint8_t* __restrict__ img, int W, int H, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -276,6 +303,12 @@ void launch_gauss(const Geom& g, const Buffers& b, int n, uint8_t* clr, hipStrea
 void launch_remap_writeback(const Geom& g, const Buffers& b, int n, hipStream_t s) {
     if (!b.in_rw) return;
     const size_t total = (size_t)n * g.W * g.H;
+    if ((g.W & 15) == 0 && (reinterpret_cast<uintptr_t>(b.in_rw) & 15) == 0) {      // rows of whole 16-byte units
+        const size_t units = total >> 4;
+        const int blocks = (int)std::min<size_t>((units + 255) / 256, 16384);
+        hipLaunchKernelGGL(k_remap_inplace16, dim3(blocks), dim3(256), 0, s, b.in_rw, (uint32_t)g.W, (uint32_t)g.H, units);
+        return;
+    }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_remap_inplace, dim3(blocks), dim3(256), 0, s, b.in_rw, g.W, g.H, total);
