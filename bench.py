@@ -684,6 +684,40 @@ def extras(out, a, ctx, lsd, ldist, maps, d_maps, d_lines, d_counts, d_ims, stre
         del d_priv, rem
     except (RuntimeError, lsd.LsdError) as e:
         out["writeback_map"] = {"error": str(e)[:200]}
+    # ... and the timed configuration WITH it: every step in flight on a private copy of the batch that is restored (a device copy on the
+    # step's stream: the arrival of the next batch, which the reference's caller does by loading a file) before the step rewrites it
+    if len(ctxs) > 1 and "error" not in out["writeback_map"]:
+        try:
+            privs = [d_maps.clone() for _ in ctxs]
+            for c_ in ctxs:
+                c_.set_region_help(a.help_waves); c_.set_region_waves(waves)
+            def stepw(i, restore=True):
+                j = i % len(ctxs)
+                l_, c2, im_ = outs[j]
+                if restore:
+                    with torch.cuda.stream(tstreams[j]):
+                        privs[j].copy_(d_maps, non_blocking=True)
+                ctxs[j].enqueue_device(privs[j].data_ptr(), n_total, size, size, l_.data_ptr(), a.max_lines, c2.data_ptr(),
+                                       d_line_ims=None if im_ is None else im_.data_ptr(), flags=lsd.LSD_FLAG_WRITEBACK_MAP, stream=tstreams[j].cuda_stream)
+            res_w = {}
+            for restore in (True, False):                  # (False: the same steps without the restoring copy -- on maps that are already rewritten: the copy's own share)
+                for i in range(len(ctxs)):
+                    stepw(i, restore)
+                torch.cuda.synchronize()
+                ks = 24
+                t1 = time.perf_counter()
+                for i in range(ks):
+                    stepw(i, restore)
+                torch.cuda.synchronize()
+                res_w[restore] = (time.perf_counter() - t1) / ks * 1e3
+            out["writeback_map"].update({"timed_configuration_ms_per_step_with_writeback_and_restore_copy": res_w[True],
+                                         "timed_configuration_ms_per_step_with_writeback_no_restore": res_w[False],
+                                         "timed_configuration_note": "%d steps in flight as in the timed region, 24 steps after a fill, LSD_FLAG_WRITEBACK_MAP on a private copy per slot; "
+                                                                     "'no_restore' runs on maps already rewritten (other work, shown for the copy's share only)" % len(ctxs)})
+            del privs
+            ctx.set_region_help(-1); ctx.set_region_waves(0)
+        except (RuntimeError, lsd.LsdError) as e:
+            out["writeback_map"]["timed_configuration_error"] = str(e)[:200]
     # -- mapValue_map1 (608 x 480, 7 lines): (a) the reference's usage, ONE host-ABI call createMapCache + myLineSegmentDetector
     #    (LSD/main_on_windows.cpp:67-70), wall time incl. PCIe; (b) throughput on 512 replicas resident in HBM
     m1 = maps["map1"]

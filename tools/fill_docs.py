@@ -11,6 +11,18 @@ long_run = None
 lp = src.replace("_bench_n1.json", "_bench_n1_steps128.json")
 if lp != src and os.path.exists(lp):
     long_run = json.load(open(lp))
+# the DRIVER's measurement of the previous round next to the builder's own: K2's fraction moves with the box (0.43-0.51), and the
+# driver's number is the one that is judged
+import glob
+drv = "n/a"
+prev = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))
+if prev:
+    try:
+        pj = json.load(open(prev[-1])).get("parsed") or {}
+        drv = "`%s`: %.1f Gpix/s, %.1f ms per step; `roofline.frac` **%.3f** (K2 launch %.3f ms)" % (
+            os.path.basename(prev[-1]), pj["value"] / 1e3, pj["ms_per_step"], pj["roofline"]["frac"], pj["roofline"]["avg_launch_ms"])
+    except Exception as e:
+        drv = "n/a (%r)" % e
 rows = [
     ("source", "`%s` (`python3 bench.py`, kernel sources sha %s)" % (os.path.relpath(src, ROOT), j.get("source_sha"))),
     ("timed region", "%d steps in flight, %d-wave region stage, help %s, %d timed steps after %d warm-up steps" % (
@@ -26,6 +38,7 @@ rows = [
         j["kernel_ms_in_timed_region"][x] for x in ("gauss", "gradient", "sort", "lines"))) if j.get("kernel_ms_in_timed_region") else ("front end in the timed region", "n/a"),
     ("`roofline` (K2)", "%.0f GB/s algorithmic = **%.3f** of 8 TB/s (launch %.3f ms); PMC traffic %s GB per launch; device copy in the same process %s GB/s" % (
         rf["achieved"], rf["frac"], rf["avg_launch_ms"], "%.2f" % (rf["traffic"] / 1e9) if rf.get("traffic") else "n/a", "%.0f" % rf["measured_copy_GBs"] if "measured_copy_GBs" in rf else "n/a")),
+    ("... the driver's own line of the round before (other box, same kernel)", drv),
     ("K4 cycles per image", "alone (8 waves, the library's defaults): mean %.1f M, max %.1f M; timed region (%s): mean %.1f M, max %.1f M" % (
         dk["cycles_per_image"]["mean"] / 1e6, dk["cycles_per_image"]["max"] / 1e6, dk["timed_region"]["variant"], dk["timed_region"]["cycles_per_image"]["mean"] / 1e6, dk["timed_region"]["cycles_per_image"]["max"] / 1e6)),
     ("whole step vs HBM", "%.1f GB algorithmic per step -> %.0f GB/s = %.3f of peak (`roofline_pipeline`)" % (j["roofline_pipeline"]["algorithmic_bytes_per_step"] / 1e9, j["roofline_pipeline"]["achieved"], j["roofline_pipeline"]["frac"])),
@@ -40,6 +53,18 @@ if cb:
     ac = cb.get("all_cores", {})
     rows.append(("`cpu_baseline` (port)", "one pinned core %.1f Mpix/s (%.1f k lines/s); %s cores %.0f Mpix/s, per core %.2f of one core alone; GPU / port: %.0f x one core, %.1f x all usable cores" % (
         cb["value"], cb["lines_per_s"] / 1e3, ac.get("cores", "?"), ac.get("value", float("nan")), ac.get("per_core_vs_one_core", float("nan")), j.get("vs_port_one_core", float("nan")), j.get("vs_port_all_cores", float("nan")))))
+rm = j.get("real_maps")
+if rm:
+    rows.append(("the reference's own maps, un-tiled, 512 copies each (`real_maps`; ms / Mpix/s / x one core of the port / answers of certified sets)",
+                 "; ".join("%s %.1f / %.0f k / %.0f x / %d" % (k, v["ms"], v["Mpix_per_s"] / 1e3, v.get("vs_port_one_core", float("nan")), v["set_answers"]) for k, v in rm.items())))
+if "libm_sensitive_images" in j:
+    rows.append(("`lsd_last_sensitivity` on the batch", "%d of %d images have decisions within the libm's noise (%d such decisions, speculative evaluations included)" % (
+        j["libm_sensitive_images"], j["config"]["images_rank0"], j["libm_near_ties"])))
+wb = j.get("writeback_map")
+if wb and "step_ms_with" in wb:
+    rows.append(("the in-place remap of the caller's maps (`LSD_FLAG_WRITEBACK_MAP`, not in the timed region)", "K1's window %.2f -> %.2f ms one step at a time%s" % (
+        wb["gauss_ms_without"], wb["gauss_ms_with"], "; the timed configuration with it, on a private copy per step in flight restored by a device copy: %.1f ms per step (%.1f without the restoring copy)" % (
+            wb["timed_configuration_ms_per_step_with_writeback_and_restore_copy"], wb["timed_configuration_ms_per_step_with_writeback_no_restore"]) if "timed_configuration_ms_per_step_with_writeback_and_restore_copy" in wb else "")))
 p = j.get("strong_scaling_projection", {}).get("gpus")
 if p:
     lat = " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["max_shard_ms"], p[g]["speedup"]) for g in ("1", "2", "4", "8"))
