@@ -63,8 +63,8 @@ if "libm_sensitive_images" in j:
 wb = j.get("writeback_map")
 if wb and "step_ms_with" in wb:
     rows.append(("the in-place remap of the caller's maps (`LSD_FLAG_WRITEBACK_MAP`, not in the timed region)", "K1's window %.2f -> %.2f ms one step at a time%s" % (
-        wb["gauss_ms_without"], wb["gauss_ms_with"], "; the timed configuration with it, on a private copy per step in flight restored by a device copy: %.1f ms per step (%.1f without the restoring copy)" % (
-            wb["timed_configuration_ms_per_step_with_writeback_and_restore_copy"], wb["timed_configuration_ms_per_step_with_writeback_no_restore"]) if "timed_configuration_ms_per_step_with_writeback_and_restore_copy" in wb else "")))
+        wb["gauss_ms_without"], wb["gauss_ms_with"], "; the timed configuration with it, on a private copy per step in flight restored by a device copy before every step: %.1f ms per step" % (
+            wb["timed_configuration_ms_per_step_with_writeback_and_restore_copy"]) if "timed_configuration_ms_per_step_with_writeback_and_restore_copy" in wb else "")))
 p = j.get("strong_scaling_projection", {}).get("gpus")
 if p:
     lat = " / ".join("%s: %.1f ms (%.2f x)" % (g, p[g]["max_shard_ms"], p[g]["speedup"]) for g in ("1", "2", "4", "8"))
