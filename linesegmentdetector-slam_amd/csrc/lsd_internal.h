@@ -81,7 +81,7 @@ struct Buffers {
     int tun_soft, tun_claim, tun_feed, tun_big;   // schedule of the region stage (k_region.hip; lsd_ctx.hip has the defaults)
     uint32_t* xq;          // n x kXStride + kXHdr + n : control block of the help across workgroups (see above), null: no help
     int tun_help;          // helper wavefronts an image may have attached
-    int* pcount;           // persistent region stage (lsd_set_region_workgroups): the launch's image counter (zeroed before the launch), else null
+    int* pcount;           // persistent workgroups of the 8-wave region stage (k_region.hip: k_region; lsd_ctx.hip: tun_groups): the launch's image counter (zeroed before the launch), else null
     int nimg;              // ... and the number of images its workgroups share out
     int npool;             // workgroups at the end of the region stage's launch that own no image and help from the start (workspace slots n .. n + npool - 1)
     int tun_early;         // workgroups that may help while others still wait for a CU
