@@ -1949,6 +1949,14 @@ __device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, ui
     for (int j = threadIdx.x; j < RW / 4; j += 64 * NW) reinterpret_cast<uint32_t*>(rg.state)[j] = 0u;    // R_EMPTY
     if (threadIdx.x < kXReq) s_xk[threadIdx.x] = -1;
     if (c.sets) for (int j = threadIdx.x; j <= kSetMax; j += 64 * NW) st_l2(&c.sets[j], 0u);   // no certified set yet (labels of earlier launches carry another tag)
+    if (!pool) {
+        // this image's counter record and tile epochs start from zero (cleared here, not by fills in front of the launch: every dispatch
+        // of a batch in flight waits for a hardware pipe; lsd_ctx.hip).  Nobody touches them before the barrier behind the seed scan below;
+        // helpers of other workgroups only after this image has asked for them.
+        if (b.stats) for (int j = threadIdx.x; j < kStatWords; j += 64 * NW) b.stats[img * kStatWords + j] = 0ll;
+        const int ntile = c.tilesX * ((h + 7) >> 3);
+        for (int j = threadIdx.x; j < ntile; j += 64 * NW) c.tep[j] = 0u;
+    }
 
     const uint32_t* ord = b.ord + img * npx;
     uint32_t* seedidx = b.seedidx + img * npx;

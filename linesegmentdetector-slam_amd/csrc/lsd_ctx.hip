@@ -314,7 +314,7 @@ static int ensure_workspace_impl(lsd_ctx* c, size_t n, size_t npx, size_t gpx, i
         HIPCHK(c, re_alloc(&c->order, nn));
         HIPCHK(c, re_alloc(&c->sets, nn * 256));
         HIPCHK(c, re_alloc(&c->xq, nn * (size_t)(kXStride + 1) + kXHdr));
-        HIPCHK(c, re_alloc(&c->maxbits, nn)); HIPCHK(c, re_alloc(&c->nb, 2 * nn)); HIPCHK(c, re_alloc(&c->nseed, nn));   // (nb: [0, nn) list lengths, [nn, 2 nn) the gradient pass's near-tie counts)
+        HIPCHK(c, re_alloc(&c->maxbits, nn + (nn + 1) / 2)); HIPCHK(c, re_alloc(&c->nb, nn)); HIPCHK(c, re_alloc(&c->nseed, nn));   // (maxbits: [0, nn) the maxima, then nn int32: the gradient pass's near-tie counts -- one memset clears both)
         HIPCHK(c, re_alloc(&c->stats, nn * kStatWords)); HIPCHK(c, re_alloc(&c->rnum, nn * (size_t)region_ring() * 2));
         if (c->seeds) { HIPCHK(c, hipFree(c->seeds)); c->seeds = nullptr; c->cap_trace = false; }
         if (nn != c->cap_n) { c->cap_max_lines = 0; }
@@ -562,7 +562,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     Buffers b{};
     b.in = d_maps;
     b.in_rw = (flags & LSD_FLAG_WRITEBACK_MAP) ? d_maps : nullptr;
-    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb; b.ties = c->nb + c->cap_n;
+    b.gauss = c->gauss; b.mag = c->mag; b.deg = c->deg; b.sc = c->sc; b.pw = c->pw; b.epochmap = c->epochmap; b.sets = c->sets; b.maxbits = c->maxbits; b.nb = c->nb; b.ties = reinterpret_cast<int32_t*>(c->maxbits + c->cap_n);
     b.ord = c->ord; b.spill = c->spill; b.gcopy = c->gcopy; b.wmeta = c->wmeta; b.mcap = c->mcap; b.stamps = c->stamps; b.seedidx = c->seedidx; b.seedpos = c->seedpos; b.tepoch = c->tepoch;
     b.tm_stride = 4 * ((g.w + 7) >> 3) * ((g.h + 7) >> 3);
     b.order = c->order; b.slist = c->slist; b.gcap = c->gcap; b.id_budget = c->id_budget; b.pend = c->pend; b.rnum = c->rnum;
@@ -587,9 +587,14 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
     b.taps = c->d_taps; b.centres = c->d_centres; b.lgamma = c->d_lgamma; b.lg_count = c->lg_count; b.ptab = c->d_ptab;
     b.seeds = c->trace ? c->seeds : nullptr; b.nseed = c->nseed; b.stats = c->stats;
 
-    HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * n, s));
-    HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, s));
-    HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * (c->cap_n + (size_t)n), s));          // (list lengths and, from cap_n on, the near-tie counts)
+    // Every dispatch of a batch in flight has to get onto a hardware pipe that the launches of other batches may be holding (a region launch
+    // waits for workgroup slots for tens of milliseconds), so a batch costs as few dispatches as it can: ONE fill in front of the kernels (the
+    // gradient maxima and, behind them, the gradient pass's near-tie counts); the region stage clears its own counter records and tile epochs
+    // image by image; the line counts and list lengths are written by the kernels that own them unless the pipeline is cut short.
+    HIPCHK(c, hipMemsetAsync(c->maxbits, 0, sizeof(unsigned long long) * c->cap_n + sizeof(int32_t) * (size_t)n, s));
+    const bool full_region = c->stop_after == 0 || c->stop_after >= LSD_STAGE_REGION;
+    if (!full_region) HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, s));            // (else k_region writes every image's count)
+    if (c->stop_after != 0 && c->stop_after < LSD_STAGE_SORT) HIPCHK(c, hipMemsetAsync(c->nb, 0, sizeof(int32_t) * (size_t)n, s));   // (else k_sort writes every image's length)
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // Mat::zeros, myLSD.cpp:215: the Gaussian's tiles clear lineIm on the way where the raster is made of whole 16-byte words; else a
@@ -611,8 +616,7 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
             HIPCHK(c, hipMemsetAsync(c->epochmap, 0, c->cap_n * c->cap_npx * sizeof(uint32_t), sr));   // (the set labels carry the run number too)
             c->run_id = 1;
         }
-        HIPCHK(c, hipMemsetAsync(c->stats, 0, sizeof(long long) * kStatWords * n, sr));
-        HIPCHK(c, hipMemsetAsync(c->tepoch, 0, sizeof(uint32_t) * (size_t)n * (((g.w + 7) >> 3) * ((g.h + 7) >> 3)), sr));
+        // (the counter records and the tile epochs are cleared by the region stage itself, image by image: region_image)
         if (b.xq) HIPCHK(c, hipMemsetAsync(c->xq, 0, sizeof(uint32_t) * ((size_t)n * (kXStride + 1) + kXHdr), sr));
         // 8 wavefronts per image take a whole CU each: worth it up to four images per CU (waves_for); the per-wave workspace
         // (stamps / spill / gcopy: 12 B per scaled pixel and wave) was sized for it by ensure_workspace
@@ -804,7 +808,7 @@ int lsd_last_sensitivity(lsd_ctx* c, int n, int* near_ties) {
     std::vector<int32_t> grad((size_t)n);
     HIPCHK(c, hipMemcpy2D(reg.data(), sizeof(long long), c->stats + kStatTiesWord, sizeof(long long) * kStatWords, sizeof(long long), (size_t)n,
                           hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(grad.data(), c->nb + c->cap_n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(grad.data(), reinterpret_cast<int32_t*>(c->maxbits + c->cap_n), sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         const long long v = reg[(size_t)i] + grad[(size_t)i];
         near_ties[i] = v > 0x7fffffffll ? 0x7fffffff : (int)v;
