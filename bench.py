@@ -460,7 +460,8 @@ def main():
         dist.all_reduce(strong_err, op=dist.ReduceOp.MAX)
         if int(strong_err.item()) == 0:
             job_weak = dict(job)
-            job.update({"maps": d_shard, "n": hi_s - lo_s, "n_total": a.batch, "cap_rows": max(hi_s - lo_s, 1) * 512})
+            per_s = -(-a.batch // world)                   # the largest shard: the gathered slabs have the same size on every rank
+            job.update({"maps": d_shard, "n": hi_s - lo_s, "n_total": a.batch, "cap_rows": max(per_s, 1) * 512})
             for i in range(min(a.warmup, depth)):
                 step(i, False)
             barrier()
