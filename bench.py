@@ -392,7 +392,7 @@ def main():
         c_.reserve(n, size, size)
     w, h = lsd.scaled_size(size, size)
     kt = {k: 0.0 for k in ("gauss", "gradient", "sort", "region", "lines", "total")}
-    cap_rows = max(n, 1) * 512                             # slab of the per-step gather: 512 lines per image on average (flagged if exceeded)
+    cap_rows = max(-(-n_total // world), 1) * 512          # slab of the per-step gather: 512 lines per image of the LARGEST shard on average (the same on every rank; flagged if exceeded)
     # the hand-off of the line lists goes through the C ABI (lsd_gather_lines: device pack + two all-gathers on the step's stream);
     # its communicator is bound to the torch.distributed group here (RCCL), a C++ host binds it with lsd_comm_from_rccl
     comm = ldist.torch_comm() if use_dist else None
