@@ -71,3 +71,19 @@ def test_steps_in_flight_follow_the_free_hbm():
     assert bench.fit_depth(1, slot, 2e9, 1e9) == (1, None)
     d, _ = bench.fit_depth(8, slot, 2e9, 1e9)
     assert d == 1
+
+
+def test_pasted_canvas_is_seamless_and_its_oracle_answer_is_pinned(maps, oracle):
+    """bench.py's un-tiled 2048^2 workload (`real_maps.pasted2048`): three different reference maps side by side on their own background
+    value, nothing wrapped -- the maps do not touch, the canvas holds exactly their cells, and the oracle's answer on it is the one
+    recorded when the workload was added (164 lines, 13 563 raster pixels; the GPU test holds the HIP path to the oracle on it)."""
+    c = bench.make_pasted(maps, 2048)
+    assert c.shape == (2048, 2048) and c.dtype == np.uint8
+    a, b, r = maps["f3key"], maps["f4key"], np.rot90(maps["aisle3"])
+    assert int((c == 1).sum()) == int((a == 1).sum() + (b == 1).sum() + (r == 1).sum())
+    assert int((c == 255).sum()) == int((a == 255).sum() + (b == 255).sum() + (r == 255).sum())
+    assert np.array_equal(c[:a.shape[0], :a.shape[1]], a) and np.array_equal(c[990:990 + b.shape[0], :b.shape[1]], b)
+    assert not c[a.shape[0]:990, :2048 - r.shape[1]].any() and not c[:, a.shape[1]:2048 - r.shape[1]].any()      # the gaps between the maps are background
+    assert bench.make_pasted(maps, 1024) is None
+    res = oracle.lsd(c.copy(), want_lineim=True)
+    assert len(res["lines"]) == 164 and int((res["lineIm"] != 0).sum()) == 13563
