@@ -2492,6 +2492,12 @@ __device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, ui
     bool gld = false;                                       // this lane's group waits for its window
     unsigned long long gldm = 0ull;                         // bit 8g: group g waits for its window (wave-uniform)
     int gld_age = 0;                                        // steps since the fetch
+// Steps of the small-region groups a wave takes in a row before it goes back to the top of its loop (the cursor, the help protocol, the
+// hand-out: ~100 instructions that find nothing new while no group has finished and no window is awaited).  1 / 4 / 16: 31.2 / 30.9 /
+// 30.8 ms per step with eight steps in flight (profiles/r06n_inner_steps.log).
+#ifndef LSD_REGION_INNER
+#define LSD_REGION_INNER 16
+#endif
 #ifndef LSD_REGION_WINAGE
 #define LSD_REGION_WINAGE 2
 #endif
@@ -2677,6 +2683,8 @@ __device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, ui
         }
         if (gldm && (ballot64(gk >= 0 && !gld) == 0ull || ++gld_age >= kWinAge)) window_arrived();
         if (ballot64(gk >= 0)) {
+          // (up to kInnerSteps steps in a row while no group finishes and no window is awaited: nothing the top of the loop looks at changes)
+          for (int inner = 0; ; inner++) {
             // ---- one step: every active group tests the 8 neighbours of its next list entry ----
             const bool act = gk >= 0 && !gld;
             const uint32_t e = slst[act ? gi : 0];
@@ -2747,6 +2755,8 @@ __device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, ui
                 adv = true;
             }
             DSTAT(ST_SMALLSTEPS, 1);
+            if (finm || gldm || inner >= LSD_REGION_INNER - 1) break;
+          }
             LT(ST_TSMALL);
             nwait = 0;
             continue;
