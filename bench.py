@@ -574,7 +574,7 @@ def main():
                        "rccl_gather_in_step": bool(use_dist),
                        "steps_in_flight": depth, "steps_in_flight_asked": depth_asked, "steps_in_flight_note": depth_note,
                        "hbm_bytes_per_slot": slot_bytes, "region_waves_per_image": waves if waves else 8,
-                       "help_across_workgroups": bool(depth == 1 or a.help_waves),
+                       "help_across_workgroups": bool(a.help_waves),
                        # the last steps of the timed region run with the help ON: nothing follows them that could fill the idle CUs
                        "last_steps_with_help": tail_help,
                        # the steps in flight share one resident input, so the timed region runs WITHOUT LSD_FLAG_WRITEBACK_MAP: the
@@ -583,7 +583,7 @@ def main():
             # the timed region keeps `steps_in_flight` steps in flight (one context, stream and set of output buffers each);
             # `one_step_at_a_time` is the same step run alone, measured right after it -- the source of every per-kernel figure below
             "one_step_at_a_time": {"steps": un_steps, "ms_per_step": un_step_s * 1e3, "value": mpix / un_step_s, "unit": "Mpix/s",
-                                   "note": "a batch alone on the GPU, the library's defaults (8 waves per image; help across workgroups only for calls of up to 64 images); kernel_ms, roofline and dominant_kernel are from these steps "
+                                   "note": "a batch alone on the GPU, the library's defaults (8 waves per image as persistent workgroups, help across workgroups off); kernel_ms, roofline and dominant_kernel are from these steps "
                                            "(HIP events of a launch inside an overlapped region also time its wait for a CU)" if depth > 1 else "identical to the timed region"},
             "one_step_at_a_time_with_cost_history": ({"ms_per_step": hist_dt / un_steps * 1e3, "value": mpix / (hist_dt / un_steps), "unit": "Mpix/s",
                                                      "note": "lsd_set_cost_history(1): the same batch again, its images started in the order of their cost in the previous "
@@ -614,7 +614,7 @@ def main():
             "dominant_kernel": {"name": "k_region", "ms": reg_ms, "share_of_step": reg_ms / (un_step_s * 1e3),
                                 "Mpix_per_s": n * size * size / 1e6 / (reg_ms * 1e-3), "lines_per_s": float(d_counts.sum().item()) / (reg_ms * 1e-3),
                                 "bound": "serial dependence per image (no HBM / MFMA roofline applies): DESIGN.md section 4",
-                                "variant": "w8::k_region (the library's choice for one batch of this size; help across workgroups off above 64 images)" if (depth > 1 or not waves) else "w%d::k_region" % waves,
+                                "variant": "w8::k_region (the library's choice for one batch of this size: one persistent workgroup per CU; help across workgroups off)" if (depth > 1 or not waves) else "w%d::k_region" % waves,
                                 "cycles_per_image": {"mean": float(cyc.mean()), "max": float(cyc.max()), "max_over_mean": float(cyc.max() / cyc.mean()), "bad_records": bad_cyc},
                                 # the same statistics for the last step of the TIMED region (its own variant; with several steps in flight a
                                 # workgroup shares its CU with workgroups of other steps, so these cycles include that contention)

@@ -271,12 +271,13 @@ int lsd_set_trace(lsd_ctx *ctx, int on);
  * per-wave workspace (8 B per scaled pixel and wavefront + result slots) is sized for the variant. */
 int lsd_set_region_waves(lsd_ctx *ctx, int waves);
 /* Help across workgroups in the region stage: wavefronts of workgroups whose image is finished evaluate seeds of the images still
- * running (up to `waves` helper wavefronts per image; 0: none; -1, the default: 24 for calls of up to 64 images, none beyond); an image
- * asks once it has run for ~5 ms with its own wavefronts busy.  It shortens a SMALL batch (its last images no longer run on a CU each
- * with the rest of the GPU idle), and a call with up to four images also gets helper-only workgroups from the start (the reference's
- * usage, one map per call: a heavy 2048 x 2048 map 77 -> 30 ms).  In a large batch every image pays for the protocol and few are
- * helped (512 maps as one step: 83 ms with, 78 without), hence the default; a caller that keeps several batches in flight -- one
- * context and one stream per batch -- needs none either: the next batch's workgroups fill the idle CUs.  Results do not depend on it. */
+ * running (up to `waves` helper wavefronts per image; 0 or -1, the default since round 6: none); an image asks once it has run for
+ * ~5 ms with its own wavefronts busy, and a call with up to four images also gets helper-only workgroups from the start.  OFF by
+ * default: it paid while single images were dominated by long uniform structures grown again and again (round 4: a heavy 2048 x 2048
+ * map 77 -> 30 ms); since those are answered from certified sets it ties or loses at every call size (one heavy map 50.5 ms with, 49.9
+ * without; two 59.2 / 49.7; 64 maps 51.4 / 50.2; 512 maps 83 / 78; the reference's maps one per call 1.01 / 0.96 ... 6.37 / 6.36 ms:
+ * profiles/r06q_help_small_probe.log), and a caller that keeps several batches in flight needs none either.  The machinery stays
+ * available and tested (lsd_set_region_help(ctx, 24)); results do not depend on it. */
 int lsd_set_region_help(lsd_ctx *ctx, int waves);
 /* Scheduling hint: "the batches this context gets hold the same maps from call to call" (a site's maps, re-extracted as they are
  * updated).  The region stage then starts the images in descending order of the time each one took in the context's previous call with

@@ -262,7 +262,6 @@ static int waves_for(const lsd_ctx* c, int n) {
 
 // Workgroups that own no image and help from the start (k_region.hip): as many as the images leave workgroup slots of the device
 // free -- one 8-wave workgroup per CU, three 4-wave ones -- and the images' helper wavefronts (tun_help each) can use.
-constexpr int kHelpDefaultImages = 64;  // calls with more images run without help across workgroups unless lsd_set_region_help asks for it
 constexpr int kPoolHelpMax = 64;        // helper wavefronts per image the pool is sized for at most (workspace: a wave slot each)
 static int pool_for(const lsd_ctx* c, int n, int help) {
     if (help < 0) help = 24;
@@ -575,10 +574,12 @@ int lsd_enqueue_batch_device(lsd_ctx* c, uint8_t* d_maps, int n, int cols, int r
         b.tun_claim = c->tun_claim > 0 ? c->tun_claim : 192 * nw;
         b.tun_feed = c->tun_feed;
         b.tun_big = c->tun_big > 0 ? c->tun_big : 3;
-        // help across workgroups by default only for calls of up to kHelpDefaultImages images: measured on the bench maps (round 5, one step at
-        // a time on 8 waves, profiles/r05y_onestep_n.log) 16 / 64 images: 39 / 51 ms with or without; 128 / 256 / 384 / 512 images:
-        // 56 / 61 / 71 / 83 ms with, 51 / 54 / 66 / 78 without -- every image of a large batch pays for the protocol and few are helped
-        b.tun_help = c->tun_help >= 0 ? c->tun_help : (n <= kHelpDefaultImages ? 24 : 0);
+        // Help across workgroups is OFF unless lsd_set_region_help asks for it (round 6).  Round 5 had already taken it away from calls of more
+        // than 64 images (every image of a large batch pays for the protocol and few are helped: 512 maps 83 ms with, 78 without).  Since the
+        // certified sets answer the structures that used to make single images heavy, it loses or ties everywhere else too
+        // (profiles/r06q_help_small_probe.log, 2048^2 bench images, with / without): 1 image 8.9 / 8.9 ms, a heavy one 50.5 / 49.9; 2 heavy
+        // images 59.2 / 49.7; 4: 55.9 / 48.5; 16: 39.1 / 37.2; 64: 51.4 / 50.2; the reference's maps one per call 1.01 / 0.96 ... 6.37 / 6.36 ms.
+        b.tun_help = c->tun_help >= 0 ? c->tun_help : 0;
         b.tun_early = c->tun_early; b.tun_wb = c->tun_wb; b.tun_gate = c->tun_gate; b.tun_share = c->tun_share; b.tun_up = c->tun_up; b.tun_down = c->tun_down; b.tun_requeue = c->tun_requeue;
         b.tun_xpoll = c->tun_xpoll; b.tun_linger = c->tun_linger; b.tun_stop = c->tun_stop;
         b.xq = (b.tun_help > 0 && !c->trace) ? c->xq : nullptr;

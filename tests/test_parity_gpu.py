@@ -1129,6 +1129,7 @@ def test_helper_pool_on_single_images_is_repeatable(maps, lsdmod, oracle):
     import bench
     cases = [("bench187", bench.make_image(maps, 187, 2048)), ("f4key", maps["f4key"]), ("f3key", maps["f3key"])]
     on, off = lsdmod.Context(0), lsdmod.Context(0)
+    on.set_region_help(24)                                                    # (off by default since round 6: the pool has to be asked for)
     off.set_region_help(0)
     try:
         for name, img in cases:
@@ -1207,8 +1208,8 @@ def test_help_across_workgroups_changes_nothing(waves, maps, lsdmod, oracle):
 
 
 def test_large_batches_run_without_help_by_default(maps, lsdmod, oracle):
-    """Help across workgroups is the default for calls of up to 64 images only (lsd_ctx.hip: kHelpDefaultImages): in a larger batch
-    no image exports a seed unless lsd_set_region_help asks for it -- and asking changes no byte of the result."""
+    """Help across workgroups is off unless lsd_set_region_help asks for it (since round 6 at every call size): no image exports a
+    seed by default -- and asking changes no byte of the result."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     heavy = bench.make_image(maps, 27, 2048)[:1024, :1024]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: randomized parity campaign in BATCH mode -- groups of random synthetic maps of one size (walls, noise, random
-parameters per group) run as one batch with the help across workgroups on (default settings), both region-stage variants, and
+parameters per group) run as one batch with the help across workgroups on (lsd_set_region_help 24), both region-stage variants, and
 compared image by image with the oracle.  Exercises what the single-image campaign (tools/campaign.py) cannot: helpers from finished
 workgroups, several images' commit machinery at once.     tools/campaign_batch.py [groups] [images per group]"""
 import importlib, os, sys, time
@@ -12,6 +12,7 @@ from oracle import oracle
 lsd = importlib.import_module("linesegmentdetector-slam_amd")
 oracle.build()
 ctx = lsd.Context(0)
+ctx.set_region_help(24)                                    # (off by default since round 6: this campaign is about the help protocol)
 groups = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 
