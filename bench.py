@@ -552,10 +552,10 @@ def main():
         stats = [ctx.fetch(i, lsd.DBG_STATS, (w, h)) for i in range(n)]
         ties = ctx.last_sensitivity(n)                      # decisions within the noise of the reference's libm, per image (lsd_last_sensitivity)
         cyc_raw = np.array([x["cycles_total"] for x in stats], np.int64)
-        # (a record that is not a positive clock count is left out of the statistics and listed, so that it shows instead of skewing a mean.
-        #  Seen once, in a six-image run started by the test suite while the suite's own process held the GPU too: the count is a difference
-        #  of the shader clock, s_memtime, and a wavefront that was preempted -- two processes time-slicing the device -- and resumed on another
-        #  XCD reads another counter.  Never seen with the device to itself.)
+        # (a record that is not a positive clock count is left out of the statistics and listed.  The count is a difference of the shader clock,
+        #  s_memtime, which is a counter of the XCD: a workgroup that was preempted -- more hardware queues in use than the device has, e.g. this
+        #  process beside another -- and resumed elsewhere read another counter; the kernel falls back to the constant 100 MHz clock then, so
+        #  that none should show up here any more)
         bad_cyc = [(int(i), int(v)) for i, v in enumerate(cyc_raw) if v <= 0]
         cyc = cyc_raw[cyc_raw > 0].astype(np.float64) if (cyc_raw > 0).any() else np.ones(1)
         nb_mean = float(np.mean([ctx.fetch(i, lsd.DBG_NB, (w, h)) for i in range(0, n, max(1, n // 32))]))

@@ -2922,7 +2922,17 @@ __device__ __forceinline__ void region_image(const Geom& g, const Buffers& b, ui
     if (b.stats && !pool) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(b.stats + img * kStatWords);
         if (lane == 0 && wave == 0 && !lds_ld(&s_abort)) { b.stats[img * kStatWords + 45] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15); b.stats[img * kStatWords + 46] = rt_begin; b.stats[img * kStatWords + 47] = (long long)__builtin_amdgcn_s_memrealtime(); }   // (developer record: when the image ran)
-        if (lane == 0 && wave == 0) { g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_begin); g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth)); }
+        if (lane == 0 && wave == 0) {
+            // shader clocks of this workgroup on the image.  s_memtime is a counter of the XCD the wavefront runs on: a workgroup that was
+            // preempted (more hardware queues in use than the device has -- e.g. two processes with 16 each -- make the scheduler time-slice
+            // them, saving and restoring wavefronts) and resumed on another XCD reads another counter, and the difference comes out negative or
+            // absurd (seen in the test suite, which starts bench.py beside its own process).  Then the constant 100 MHz clock stands in, at the
+            // nominal 24 shader clocks per tick.
+            long long tot = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+            const long long rt = ((long long)__builtin_amdgcn_s_memrealtime() - rt_begin) * 24;
+            if (tot <= 0 || tot > 4 * rt + 1000000) tot = rt > 0 ? rt : 1;
+            g_stat[c.wave][sslot(ST_TOTAL)] = (unsigned long long)tot; g_stat[c.wave][sslot(ST_SEEDS)] = (unsigned long long)nseeds; DSTAT(ST_DEPTHEND, lds_ld(&s_depth));
+        }
         if (lane < ST_COUNT && !lds_ld(&s_abort) && (sslot(lane) != 11 || lane == ST_NFASLOW || kStatSlots == ST_COUNT)) {
             if (lane == ST_MINNFA || lane == ST_MINGAP) atomicMax(&st[lane], g_stat[c.wave][sslot(lane)]);
             else atomicAdd(&st[lane], g_stat[c.wave][sslot(lane)]);
