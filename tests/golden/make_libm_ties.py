@@ -19,18 +19,20 @@ from campaign_images import campaign_image  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 SMALL = [2995, 1759, 6382, 10647, 18262, 27264, 38359, 40212, 45813, 48150, 54902, 55115, 56831, 58631,
-         68894, 73163, 75918, 79924, 80225, 80295, 83780]      # (the second row: images 60 000 .. 89 999, profiles/r05h_campaign_fresh30000.log)
+         68894, 73163, 75918, 79924, 80225, 80295, 83780,      # (the second row: images 60 000 .. 89 999, profiles/r05h_campaign_fresh30000.log)
+         90756, 92641, 96504]                                   # (images 90 000 .. 109 999, round 6: profiles/r06r_campaign_fresh20000.log)
 BIG = [297]
 # ... and the images of the campaigns with an NFA comparison inside, or within a factor two of, what an ulp of exp / log10 / pow can move (705: margin 0.27: two hopeless
 # rectangles, 5 aligned pixels of 656, whose tails are 1 - 1e-15, so that logNFA = -logNT to the last place): both builds decide alike on
 # it -- kept so that a libm (or a change of the device routines) that decides otherwise shows up
 NEAR = [705, 1854, 2331]                                  # (1854, 2331: margins 1.3 and 1.5, profiles/r05h_campaign_big_fresh600.log)
+NEAR_SMALL = [98908]                                      # (a small campaign image: two NFA values with a margin of 0.99, profiles/r06r_campaign_fresh20000.log)
 NAMES = {2995: "tie_a", 1759: "tie_b"}                     # (the two fixtures of round 3 keep their names)
 
 out, table = {}, {}
-for i, big in [(i, False) for i in SMALL] + [(i, True) for i in BIG] + [(i, True) for i in NEAR]:
+for i, big in [(i, False) for i in SMALL] + [(i, True) for i in BIG] + [(i, True) for i in NEAR] + [(i, False) for i in NEAR_SMALL]:
     img, kw, _ = campaign_image(i, big)
-    name = NAMES.get(i, "%s%d" % ("near" if i in NEAR else "big" if big else "img", i))
+    name = NAMES.get(i, "%s%d" % ("near" if (i in NEAR and big) or (i in NEAR_SMALL and not big) else "big" if big else "img", i))
     a = oracle.lsd(img.copy(), debug=True, **kw)
     b = oracle.lsd(img.copy(), debug=True, _lib=oracle.lib_cr(), **kw)
     out[name] = img
