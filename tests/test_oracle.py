@@ -246,8 +246,8 @@ LIBM_TIES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "li
 
 @pytest.mark.parametrize("name", sorted(LIBM_TIES))
 def test_libm_tie_images_document_the_one_caveat(name, oracle):
-    """tests/golden/libm_ties.npz (written by make_libm_ties.py): ALL 25 images of the random campaigns (110 000 + 2 400 large ones,
-    tools/campaign.py) on which the HIP path and the glibc-built restatement disagree, and the three with an NFA comparison below the
+    """tests/golden/libm_ties.npz (written by make_libm_ties.py): ALL 35 images of the random campaigns (160 000 + 3 900 large ones,
+    tools/campaign.py) on which the HIP path and the glibc-built restatement disagree, and the five with an NFA comparison below the
     campaign's margin floor (`near*`).  The restatement rebuilt on correctly rounded
     functions (oracle/cr_shim.cpp) differs from the glibc one in exactly the recorded way: one accept / reject decision on a
     structural tie that a 1-ulp libm difference turns; the same seeds, the same regions up to there."""

@@ -28,8 +28,8 @@ kMarginFloor = 2.0
 CR_EVERY = int(os.environ.get("CAMPAIGN_CR", "10"))          # every n-th image also SEED BY SEED against the correctly rounded restatement, NFA values to the bit
 CR_ALL = os.environ.get("CAMPAIGN_CR_ALL", "1") != "0"        # every image's usedMap / lineIm / lines also against the correctly rounded restatement
 # Large maps on which an NFA comparison's margin is below the floor and BOTH oracle builds decide alike (fixtures near705, near1854,
-# near2331, near98908 of tests/golden/libm_ties.npz): known, listed, and the only ones allowed -- a NEW image below the floor fails the campaign.
-ALLOW_MARGIN = {(True, 705), (True, 1854), (True, 2331), (False, 98908)}      # (98908: found by the fresh images of round 6 -- the check doing its work -- and a fixture since)
+# near2331, near3394, near98908 of tests/golden/libm_ties.npz): known, listed, and the only ones allowed -- a NEW image below the floor fails the campaign.
+ALLOW_MARGIN = {(True, 705), (True, 1854), (True, 2331), (True, 3394), (False, 98908)}      # (98908: found by the fresh images of round 6 -- the check doing its work -- and a fixture since)
 bad = cr_bad = cr_n = hard = 0
 prop_bad = sens = margin_bad = 0
 nfa_abs, nfa_gap = float('inf'), float('inf')      # smallest margins of the campaign's NFA comparisons
